@@ -1,0 +1,180 @@
+/*
+ * pathtrace_amd.h -- C ABI of the MI355X-native wavefront path tracer.
+ *
+ * Drop-in boundary for the per-pixel rendering hot path of roxas1533/pathtrace.
+ * The reference has no FFI; the seam it offers is the Rust-internal call
+ *     world_clone.render_pixel(x, y, &mut rng) -> Color        (src/main.rs:55,
+ *                                                                src/world.rs:293)
+ * inside the rayon loop at src/main.rs:43-60, plus the two film buffers
+ * World.data (RGBA8, src/world.rs:55) and World.luminance_data (linear RGB,
+ * src/world.rs:57).  pt_render() replaces that whole loop: one blocking call,
+ * internally asynchronous on HIP streams.
+ *
+ * Only plain pointers, sizes and POD cross this boundary (no trait objects, no
+ * torch types).  Reals are f64 on the boundary because the reference's
+ * Vector3 is f64 (src/math.rs:4-8); the device computes in f32.
+ *
+ * Every function returns 0 on success and a non-zero PtStatus on failure;
+ * pt_last_error() returns a thread-local message.  Nothing throws or aborts
+ * across the boundary (the reference panics instead: src/main.rs:59,66).
+ */
+#ifndef PATHTRACE_AMD_H
+#define PATHTRACE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = 1,
+    PT_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime failure at init   */
+    PT_ERR_HIP = 3,         /* a HIP call failed; see pt_last_error()         */
+    PT_ERR_OOM = 4,
+    PT_ERR_UNSUPPORTED = 5
+} PtStatus;
+
+/* ---- scene description -------------------------------------------------- */
+
+/* = the cached fields of Camera (src/camera.rs:27-39).  Fill with
+ * pt_camera_new / pt_camera_look_at, or by hand.                            */
+typedef struct {
+    double origin[3];
+    double lower_left[3];
+    double horizontal[3];
+    double vertical[3];
+    uint32_t width, height;
+} PtCamera;
+
+/* Shape tags: which `impl Shape` (src/objects/shape.rs:52,160). */
+enum { PT_SHAPE_SPHERE = 0, PT_SHAPE_TRIANGLE = 1 };
+/* Material tags: which `impl Material` (src/objects/material.rs:85,138,220;
+ * src/objects/mirror.rs:178). */
+enum { PT_MAT_LAMBERT = 0, PT_MAT_EMISSIVE = 1, PT_MAT_MIRROR = 2, PT_MAT_OREN_NAYAR = 3 };
+
+/* = Object{shape: Box<dyn Shape>, material: Box<dyn Material>}
+ * (src/objects/object.rs:9-14) flattened to POD.  Array order == World.objects
+ * order (it decides closest-hit ties, src/world.rs:281-287).
+ *   shape:  sphere   = center[3], radius            (shape.rs:38-43)
+ *           triangle = v0[3], v1[3], v2[3]          (shape.rs:148-152)
+ *   mat:    lambert    = albedo[3]                  (material.rs:67-69)
+ *           emissive   = emission[3]                (material.rs:126-129)
+ *           mirror     = roughness, color[3], metallic, ior   (mirror.rs:5-14)
+ *           oren-nayar = albedo[3], roughness       (material.rs:166-174)     */
+typedef struct {
+    uint32_t shape_tag;
+    uint32_t mat_tag;
+    double shape[9];
+    double mat[6];
+} PtObject;
+
+enum { PT_INTEGRATOR_MIS = 0, PT_INTEGRATOR_BRDF_ONLY = 1 };
+
+/* Compile-time constants of the reference made runtime parameters
+ * (src/world.rs:16-18, src/rendering.rs:6-10).  pt_default_params() fills the
+ * reference's values.                                                        */
+typedef struct {
+    uint32_t spp;            /* SAMPLE_NUM (world.rs:18)                       */
+    uint32_t spp_offset;     /* first sample index; film is linear in spp      */
+    uint32_t min_depth;      /* MIN_DEPTH = 4 (rendering.rs:6)                 */
+    uint32_t max_depth;      /* MAX_DEPTH = 50 (rendering.rs:7)                */
+    uint32_t integrator;     /* PT_INTEGRATOR_*; cargo feature (Cargo.toml:6)  */
+    double   t_min;          /* 0.001 (rendering.rs:41,64,105)                 */
+    /* Row-band tile of the image rendered by this call: the image rows are cut
+     * into bands of band_rows rows; this call renders bands b with
+     * b % band_count == band_index.  band_count = 1 renders the whole image.
+     * Output buffers hold only this tile's rows, ascending y, row-major.      */
+    uint32_t band_rows;
+    uint32_t band_index;
+    uint32_t band_count;
+    /* Wavefront sizing: upper bound on paths resident in HBM at once
+     * (0 = library default).                                                  */
+    uint64_t max_paths_in_flight;
+    uint32_t profile;        /* 1: time every bounce launch with HIP events    */
+    uint32_t reserved;
+} PtRenderParams;
+
+/* Counters of the last render on a context. */
+typedef struct {
+    uint64_t samples;          /* camera samples traced = tile pixels * spp    */
+    uint64_t vertices;         /* path vertices processed (iterations of the
+                                  per-vertex loop)                 */
+    uint64_t shadow_rays;      /* NEE visibility scans                         */
+    uint32_t bounce_launches;  /* bounce-kernel launches                       */
+    uint32_t batches;          /* sample batches                               */
+    uint32_t max_depth_reached;
+    uint32_t reserved;
+    double   bounce_kernel_ms; /* sum of HIP-event durations of the bounce
+                                  kernel launches (profile=1), else 0         */
+    double   total_ms;         /* HIP-event duration of the whole render      */
+} PtStats;
+
+/* ---- helpers ------------------------------------------------------------ */
+
+/* Camera::new (src/camera.rs:50-82): axis aligned, looks down -Z. */
+int pt_camera_new(const double origin[3], uint32_t width, uint32_t height,
+                  double screen_distance, double fov_degrees, PtCamera* out);
+/* Camera::look_at (src/camera.rs:94-130). */
+int pt_camera_look_at(const double origin[3], const double target[3], const double up[3],
+                      uint32_t width, uint32_t height, double fov_degrees, PtCamera* out);
+/* Reference constants: spp 3000, min_depth 4, max_depth 50, MIS, t_min 1e-3. */
+void pt_default_params(PtRenderParams* out);
+/* Number of image rows in the tile selected by (band_rows, band_index, band_count). */
+uint32_t pt_tile_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count);
+
+/* Built-in scenes: 1 = World::new() Cornell box, verbatim
+ * src/world.rs:80-211; 2 = 10-sphere diffuse Cornell; 4 = n random spheres
+ * (arg = n, 0 -> 10000).  Writes up to cap objects, returns the count in *n
+ * (call with objs = NULL to query).                                          */
+int pt_builtin_scene(uint32_t id, uint32_t arg, PtObject* objs, uint32_t cap, uint32_t* n);
+
+/* ---- rendering ---------------------------------------------------------- */
+
+typedef struct PtContext PtContext;
+
+/* One context per process per GPU.  device = HIP device ordinal. */
+int pt_context_create(int device, PtContext** out);
+int pt_context_destroy(PtContext* ctx);
+/* Run the library's kernels on a caller-owned hipStream_t (e.g. torch's current
+ * stream) instead of the context's own stream.  NULL restores the default.    */
+int pt_context_set_stream(PtContext* ctx, void* hip_stream);
+
+/* Copy the scene to the device (the reference's World is immutable while
+ * rendering: render_pixel(&self), src/world.rs:293).  Lights are detected as
+ * in src/world.rs:214-225: objects whose emit() has non-zero length.          */
+int pt_scene_upload(PtContext* ctx, const PtObject* objs, uint32_t n_objs);
+
+/* Render the tile into DEVICE buffers (no host transfer inside):
+ *   d_linear_rgb: float[tile_rows*W*3], mean linear radiance  (= luminance_data,
+ *                 src/world.rs:318-319)
+ *   d_rgba8:      uint8[tile_rows*W*4], sqrt-gamma + truncation (= World.data /
+ *                 draw(), src/world.rs:322-341); may be NULL.
+ * Asynchronous on the context's stream; pt_sync() waits.                      */
+int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
+                     float* d_linear_rgb, uint8_t* d_rgba8);
+int pt_sync(PtContext* ctx);
+int pt_get_stats(PtContext* ctx, PtStats* out);
+
+/* One-shot convenience with HOST buffers: create context on device 0 (cached),
+ * upload, render, copy back.  = everything src/main.rs:43-60 does.            */
+int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n_objs,
+              const PtRenderParams* params, float* out_linear_rgb, uint8_t* out_rgba8);
+
+/* Debug/parity entry: closest-hit scan of World::hit_scene (src/world.rs:270-290)
+ * on the device for n arbitrary rays (host arrays; rays = n*6 doubles o,d; the
+ * direction is normalised on entry like Ray::new, src/camera.rs:10-16).
+ * out_id[i] = object index or -1, out_t[i] = hit distance.                   */
+int pt_debug_hit_scene(PtContext* ctx, const double* rays, uint32_t n,
+                       double t_min, double t_max, int32_t* out_id, float* out_t);
+
+const char* pt_last_error(void);
+uint32_t pt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHTRACE_AMD_H */

@@ -1,0 +1,257 @@
+// oracle_capi.cpp -- C entry points of the CPU ORACLE (test infrastructure only;
+// see the header of pt_oracle.hpp for who may use it and what pins it).
+//
+// Modes of orc_render: precision {f64, f32} x form {recursive, iterative}.
+//   f64 recursive  = the reference-faithful restatement (rendering.rs:34-142).
+//   f32 iterative  = the device-equivalent computation.
+// Threads: a std::thread pool over pixels mirroring rayon's par_iter
+// (src/main.rs:48); threads=1 is the scalar port.
+#include <atomic>
+#include <cstdio>
+#include <thread>
+
+#include "pt_oracle.hpp"
+
+using namespace orc;
+
+namespace {
+
+template <class R> Camera<R> make_camera(const PtCamera* c) {
+    Camera<R> cam;
+    cam.origin = V3<R>((R)c->origin[0], (R)c->origin[1], (R)c->origin[2]);
+    cam.lower_left = V3<R>((R)c->lower_left[0], (R)c->lower_left[1], (R)c->lower_left[2]);
+    cam.horizontal = V3<R>((R)c->horizontal[0], (R)c->horizontal[1], (R)c->horizontal[2]);
+    cam.vertical = V3<R>((R)c->vertical[0], (R)c->vertical[1], (R)c->vertical[2]);
+    cam.width = c->width; cam.height = c->height;
+    return cam;
+}
+
+Params make_params(const PtRenderParams* p) {
+    Params q;
+    q.min_depth = p->min_depth; q.max_depth = p->max_depth;
+    q.integrator = p->integrator; q.t_min = p->t_min;
+    return q;
+}
+
+template <class R>
+int render_impl(const PtCamera* pc, const PtObject* objs, uint32_t n, const PtRenderParams* pp, int form, int threads,
+                double* out_lin, uint8_t* out_rgba, uint64_t* out_counters) {
+    Scene<R> scene = build_scene<R>(objs, n);
+    Camera<R> cam = make_camera<R>(pc);
+    Params prm = make_params(pp);
+    std::vector<uint32_t> rows = tile_rows(pc->height, pp->band_rows, pp->band_index, pp->band_count);
+    const uint32_t W = pc->width;
+    const size_t npix = rows.size() * (size_t)W;
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next{0};
+    std::vector<Counters> cns(threads);
+    auto worker = [&](int tid) {
+        Counters& cn = cns[tid];
+        const size_t chunk = 64;
+        for (;;) {
+            size_t b = next.fetch_add(chunk);
+            if (b >= npix) break;
+            size_t e = b + chunk < npix ? b + chunk : npix;
+            for (size_t i = b; i < e; ++i) {
+                uint32_t yl = (uint32_t)(i / W), x = (uint32_t)(i % W);
+                uint32_t y = rows[yl];
+                double lin[3]; uint8_t rg[4];
+                render_pixel<R>(scene, cam, prm, (Form)form, x, y, pp->spp, pp->spp_offset, lin, rg, cn);
+                if (out_lin) { out_lin[i * 3] = lin[0]; out_lin[i * 3 + 1] = lin[1]; out_lin[i * 3 + 2] = lin[2]; }
+                if (out_rgba) std::memcpy(out_rgba + i * 4, rg, 4);
+            }
+        }
+    };
+    if (threads == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t) th.emplace_back(worker, t);
+        for (auto& t : th) t.join();
+    }
+    if (out_counters) {
+        uint64_t v = 0, s = 0, sc = 0; uint32_t md = 0;
+        for (auto& c : cns) { v += c.vertices; s += c.shadow_rays; sc += c.scans; if (c.max_depth > md) md = c.max_depth; }
+        out_counters[0] = v; out_counters[1] = s; out_counters[2] = sc; out_counters[3] = md;
+    }
+    return 0;
+}
+
+}  // namespace
+
+
+// precision: 64 or 32; form: 0 recursive, 1 iterative.
+// out_lin: double[tile_pixels*3]; out_rgba: uint8[tile_pixels*4]; out_counters: u64[4]
+// = {vertices, shadow_rays, scans, max_depth}.
+extern "C" int orc_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRenderParams* p, int precision, int form,
+               int threads, double* out_lin, uint8_t* out_rgba, uint64_t* out_counters) {
+    if (!cam || !objs || !p || p->spp == 0) return 1;
+    if (precision == 64) return render_impl<double>(cam, objs, n, p, form, threads, out_lin, out_rgba, out_counters);
+    return render_impl<float>(cam, objs, n, p, form, threads, out_lin, out_rgba, out_counters);
+}
+
+extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+extern "C" double orc_u01(uint32_t r) { return u01(r); }
+
+extern "C" void orc_camera_new(const double o[3], uint32_t w, uint32_t h, double dist, double fov, PtCamera* out) {
+    camera_new(o, w, h, dist, fov, out);
+}
+extern "C" void orc_camera_look_at(const double o[3], const double t[3], const double up[3], uint32_t w, uint32_t h, double fov,
+                        PtCamera* out) {
+    camera_look_at(o, t, up, w, h, fov, out);
+}
+
+// Camera::get_ray_with_offset for n (x, y, ox, oy) tuples -> rays n*6 (o, d).
+extern "C" void orc_camera_rays(const PtCamera* pc, int precision, uint32_t n, const uint32_t* xy, const double* off,
+                     double* rays) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (precision == 64) {
+            Ray<double> r = make_camera<double>(pc).get_ray_with_offset(xy[2 * i], xy[2 * i + 1], off[2 * i], off[2 * i + 1]);
+            double v[6] = {r.origin.x, r.origin.y, r.origin.z, r.direction.x, r.direction.y, r.direction.z};
+            std::memcpy(rays + 6 * i, v, sizeof v);
+        } else {
+            Ray<float> r = make_camera<float>(pc).get_ray_with_offset(xy[2 * i], xy[2 * i + 1], (float)off[2 * i],
+                                                                     (float)off[2 * i + 1]);
+            double v[6] = {r.origin.x, r.origin.y, r.origin.z, r.direction.x, r.direction.y, r.direction.z};
+            std::memcpy(rays + 6 * i, v, sizeof v);
+        }
+    }
+}
+
+// World::hit_scene on n rays (o,d as doubles; direction normalised like Ray::new).
+// out_id: object index or -1; out_t; out_pn: point(3)+normal(3); out_ff: front_face.
+template <class R>
+static void hit_scene_batch(const PtObject* objs, uint32_t nobj, const double* rays, uint32_t n, double tmin,
+                            double tmax, int32_t* out_id, double* out_t, double* out_pn, uint8_t* out_ff) {
+    Scene<R> sc = build_scene<R>(objs, nobj);
+    for (uint32_t i = 0; i < n; ++i) {
+        const double* r = rays + 6 * i;
+        Ray<R> ray(V3<R>((R)r[0], (R)r[1], (R)r[2]), V3<R>((R)r[3], (R)r[4], (R)r[5]));
+        Hit<R> h;
+        int id = hit_scene<R>(sc, ray, (R)tmin, (R)tmax, h);
+        out_id[i] = id;
+        if (out_t) out_t[i] = id >= 0 ? (double)h.t : 0.0;
+        if (out_pn) {
+            double v[6] = {h.point.x, h.point.y, h.point.z, h.normal.x, h.normal.y, h.normal.z};
+            if (id < 0) std::memset(v, 0, sizeof v);
+            std::memcpy(out_pn + 6 * i, v, sizeof v);
+        }
+        if (out_ff) out_ff[i] = id >= 0 ? (h.front_face ? 1 : 0) : 0;
+    }
+}
+extern "C" void orc_hit_scene(const PtObject* objs, uint32_t nobj, int precision, const double* rays, uint32_t n, double tmin,
+                   double tmax, int32_t* out_id, double* out_t, double* out_pn, uint8_t* out_ff) {
+    if (precision == 64) hit_scene_batch<double>(objs, nobj, rays, n, tmin, tmax, out_id, out_t, out_pn, out_ff);
+    else hit_scene_batch<float>(objs, nobj, rays, n, tmin, tmax, out_id, out_t, out_pn, out_ff);
+}
+
+// Shape::sample_surface_from_point for object `obj` from n points.
+// in: from n*3, target n*3 or NULL (then uses r12 n*2).  out: n*11 =
+// point3 normal3 pdf dir3 dist.
+template <class R>
+static void shape_sample_batch(const PtObject* po, const double* from, const double* target, const double* r12,
+                               uint32_t n, double* out) {
+    Scene<R> sc = build_scene<R>(po, 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        Hit<R> f; f.point = V3<R>((R)from[3 * i], (R)from[3 * i + 1], (R)from[3 * i + 2]);
+        Hit<R> tg;
+        if (target) tg.point = V3<R>((R)target[3 * i], (R)target[3 * i + 1], (R)target[3 * i + 2]);
+        V3<R> p, nn, d; R pdf, dist;
+        shape_sample<R>(sc.objs[0], f, target ? &tg : nullptr, r12 ? (R)r12[2 * i] : R(0), r12 ? (R)r12[2 * i + 1] : R(0),
+                        p, nn, pdf, d, dist);
+        double v[11] = {p.x, p.y, p.z, nn.x, nn.y, nn.z, (double)pdf, d.x, d.y, d.z, (double)dist};
+        std::memcpy(out + 11 * i, v, sizeof v);
+    }
+}
+extern "C" void orc_shape_sample(const PtObject* po, int precision, const double* from, const double* target, const double* r12,
+                      uint32_t n, double* out) {
+    if (precision == 64) shape_sample_batch<double>(po, from, target, r12, n, out);
+    else shape_sample_batch<float>(po, from, target, r12, n, out);
+}
+
+// Material::bsdf_pdf for object `obj`: in n*(dir_in3, wo3, normal3, eta); out n*4 (f3, pdf)
+template <class R> static void bsdf_eval_batch(const PtObject* po, const double* in, uint32_t n, double* out) {
+    Scene<R> sc = build_scene<R>(po, 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        const double* q = in + 10 * i;
+        Ray<R> ray; ray.direction = V3<R>((R)q[0], (R)q[1], (R)q[2]); ray.eta_ratio = (R)q[9];
+        V3<R> wo((R)q[3], (R)q[4], (R)q[5]), nn((R)q[6], (R)q[7], (R)q[8]);
+        V3<R> f; R pdf;
+        bsdf_pdf<R>(sc.objs[0], ray, wo, nn, f, pdf);
+        double v[4] = {f.x, f.y, f.z, (double)pdf};
+        std::memcpy(out + 4 * i, v, sizeof v);
+    }
+}
+extern "C" void orc_bsdf_eval(const PtObject* po, int precision, const double* in, uint32_t n, double* out) {
+    if (precision == 64) bsdf_eval_batch<double>(po, in, n, out); else bsdf_eval_batch<float>(po, in, n, out);
+}
+
+// Material::bsdf_pdf_sample: in n*(dir_in3, normal3, eta), draws n*4 u32; out n*8 (wo3, f3, pdf, cos)
+template <class R>
+static void bsdf_sample_batch(const PtObject* po, const double* in, const uint32_t* draws, uint32_t n, double* out) {
+    Scene<R> sc = build_scene<R>(po, 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        const double* q = in + 7 * i;
+        Ray<R> ray; ray.direction = V3<R>((R)q[0], (R)q[1], (R)q[2]); ray.eta_ratio = (R)q[6];
+        V3<R> nn((R)q[3], (R)q[4], (R)q[5]);
+        V3<R> wo, f; R pdf, c;
+        bsdf_pdf_sample<R>(sc.objs[0], ray, nn, draws + 4 * i, wo, f, pdf, c);
+        double v[8] = {wo.x, wo.y, wo.z, f.x, f.y, f.z, (double)pdf, (double)c};
+        std::memcpy(out + 8 * i, v, sizeof v);
+    }
+}
+extern "C" void orc_bsdf_sample(const PtObject* po, int precision, const double* in, const uint32_t* draws, uint32_t n,
+                     double* out) {
+    if (precision == 64) bsdf_sample_batch<double>(po, in, draws, n, out);
+    else bsdf_sample_batch<float>(po, in, draws, n, out);
+}
+
+// sin/cos(2*pi*u) in the given arithmetic mode (pins the f32 polynomial against libm).
+extern "C" void orc_sincos2pi(int precision, const double* u, uint32_t n, double* out_sc) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (precision == 64) { double s, c; Ar<double>::sincos2pi(u[i], s, c); out_sc[2 * i] = s; out_sc[2 * i + 1] = c; }
+        else { float s, c; Ar<float>::sincos2pi((float)u[i], s, c); out_sc[2 * i] = s; out_sc[2 * i + 1] = c; }
+    }
+}
+
+// Vector3 KAT surface (math.rs): op on doubles a,b, scalar s -> out[3], returns scalar result.
+// ops: 0 add 1 sub 2 mul_s 3 mul_v 4 div_s 5 neg 6 dot 7 cross 8 length 9 normalize
+//      10 normal_from_triangle(a,b,c) 11 reflect 12 refract (ret 0 = None) 13 face_forward
+//      14 max 15 luminance 16 div_v 17 length_squared
+extern "C" double orc_vec3(int precision, int op, const double* a, const double* b, const double* c, double s, double* out) {
+    auto run = [&](auto tag) -> double {
+        using R = decltype(tag);
+        V3<R> A((R)a[0], (R)a[1], (R)a[2]), B, C, O;
+        if (b) B = V3<R>((R)b[0], (R)b[1], (R)b[2]);
+        if (c) C = V3<R>((R)c[0], (R)c[1], (R)c[2]);
+        double ret = 1.0;
+        switch (op) {
+            case 0: O = A + B; break;
+            case 1: O = A - B; break;
+            case 2: O = A * (R)s; break;
+            case 3: O = A * B; break;
+            case 4: O = A / (R)s; break;
+            case 5: O = -A; break;
+            case 6: ret = (double)A.dot(B); break;
+            case 7: O = A.cross(B); break;
+            case 8: ret = (double)A.length(); break;
+            case 9: O = A.normalize(); break;
+            case 10: O = V3<R>::normal_from_triangle(A, B, C); break;
+            case 11: O = A.reflect(B); break;
+            case 12: ret = A.refract(B, (R)s, O) ? 1.0 : 0.0; break;
+            case 13: O = A.face_forward(B); break;
+            case 14: ret = (double)A.max(); break;
+            case 15: ret = (double)A.luminance(); break;
+            case 16: O = A.div_vec(B); break;
+            case 17: ret = (double)A.length_squared(); break;
+            default: ret = -1.0;
+        }
+        if (out) { out[0] = O.x; out[1] = O.y; out[2] = O.z; }
+        return ret;
+    };
+    return precision == 64 ? run(double()) : run(float());
+}
+
+extern "C" uint32_t orc_tile_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count) {
+    return (uint32_t)tile_rows(height, band_rows, band_index, band_count).size();
+}
+

@@ -1,0 +1,120 @@
+"""ctypes binding of the CPU ORACLE (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never from pathtrace_amd/.  See oracle/pt_oracle.hpp for what pins the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborc.so")
+_lib = None
+
+F64, F32 = 64, 32
+RECURSIVE, ITERATIVE = 0, 1
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `make -C oracle` (or __graft_entry__.build())")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_u01.restype = C.c_double
+        _lib.orc_u01.argtypes = [C.c_uint32]
+        _lib.orc_vec3.restype = C.c_double
+        _lib.orc_vec3.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        _lib.orc_tile_rows.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def u01(r):
+    return lib().orc_u01(C.c_uint32(r))
+
+
+def render(cam, objs, params, precision=F64, form=RECURSIVE, threads=1):
+    """-> (linear float64[rows,W,3], rgba uint8[rows,W,4], counters dict)"""
+    rows = lib().orc_tile_rows(C.c_uint32(cam.height), C.c_uint32(params.band_rows), C.c_uint32(params.band_index),
+                               C.c_uint32(params.band_count or 1))
+    lin = np.zeros((rows, cam.width, 3), dtype=np.float64)
+    rgba = np.zeros((rows, cam.width, 4), dtype=np.uint8)
+    cnt = np.zeros(4, dtype=np.uint64)
+    rc = lib().orc_render(C.byref(cam), objs, C.c_uint32(len(objs)), C.byref(params), C.c_int(precision),
+                          C.c_int(form), C.c_int(threads), _p(lin), _p(rgba), _p(cnt))
+    if rc:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    return lin, rgba, {"vertices": int(cnt[0]), "shadow_rays": int(cnt[1]), "scans": int(cnt[2]),
+                       "max_depth": int(cnt[3])}
+
+
+def hit_scene(objs, rays, t_min=0.001, t_max=float("inf"), precision=F64):
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    n = rays.shape[0]
+    ids = np.empty(n, dtype=np.int32)
+    ts = np.empty(n, dtype=np.float64)
+    pn = np.empty((n, 6), dtype=np.float64)
+    ff = np.empty(n, dtype=np.uint8)
+    lib().orc_hit_scene(objs, C.c_uint32(len(objs)), C.c_int(precision), _p(rays), C.c_uint32(n), C.c_double(t_min),
+                        C.c_double(t_max), _p(ids), _p(ts), _p(pn), _p(ff))
+    return ids, ts, pn, ff
+
+
+def camera_rays(cam, xy, off, precision=F64):
+    xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+    off = np.ascontiguousarray(off, dtype=np.float64).reshape(-1, 2)
+    out = np.empty((xy.shape[0], 6), dtype=np.float64)
+    lib().orc_camera_rays(C.byref(cam), C.c_int(precision), C.c_uint32(xy.shape[0]), _p(xy), _p(off), _p(out))
+    return out
+
+
+def shape_sample(obj_array, frm, target=None, r12=None, precision=F64):
+    frm = np.ascontiguousarray(frm, dtype=np.float64).reshape(-1, 3)
+    n = frm.shape[0]
+    tg = np.ascontiguousarray(target, dtype=np.float64).reshape(-1, 3) if target is not None else None
+    rr = np.ascontiguousarray(r12, dtype=np.float64).reshape(-1, 2) if r12 is not None else None
+    out = np.empty((n, 11), dtype=np.float64)
+    lib().orc_shape_sample(obj_array, C.c_int(precision), _p(frm), _p(tg), _p(rr), C.c_uint32(n), _p(out))
+    return out
+
+
+def bsdf_eval(obj_array, inp, precision=F64):
+    inp = np.ascontiguousarray(inp, dtype=np.float64).reshape(-1, 10)
+    out = np.empty((inp.shape[0], 4), dtype=np.float64)
+    lib().orc_bsdf_eval(obj_array, C.c_int(precision), _p(inp), C.c_uint32(inp.shape[0]), _p(out))
+    return out
+
+
+def bsdf_sample(obj_array, inp, draws, precision=F64):
+    inp = np.ascontiguousarray(inp, dtype=np.float64).reshape(-1, 7)
+    draws = np.ascontiguousarray(draws, dtype=np.uint32).reshape(-1, 4)
+    out = np.empty((inp.shape[0], 8), dtype=np.float64)
+    lib().orc_bsdf_sample(obj_array, C.c_int(precision), _p(inp), _p(draws), C.c_uint32(inp.shape[0]), _p(out))
+    return out
+
+
+def sincos2pi(u, precision=F32):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.empty((u.shape[0], 2), dtype=np.float64)
+    lib().orc_sincos2pi(C.c_int(precision), _p(u), C.c_uint32(u.shape[0]), _p(out))
+    return out
+
+
+def vec3(op, a, b=None, c=None, s=0.0, precision=F64):
+    A = np.asarray(a, dtype=np.float64)
+    B = np.asarray(b, dtype=np.float64) if b is not None else None
+    Cc = np.asarray(c, dtype=np.float64) if c is not None else None
+    out = np.zeros(3, dtype=np.float64)
+    ret = lib().orc_vec3(C.c_int(precision), C.c_int(op), _p(A), _p(B), _p(Cc), C.c_double(s), _p(out))
+    return ret, out

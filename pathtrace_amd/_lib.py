@@ -1,0 +1,120 @@
+"""ctypes binding of the C ABI declared in include/pathtrace_amd.h.
+
+This is the same binding a foreign-language host would write (see INTEGRATION.md
+for the Rust `extern "C"` form).  Loading fails loudly when the shared library is
+missing: there is no Python or CPU fallback for the rendering path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpathtrace_amd.so")
+
+
+class PtCamera(C.Structure):
+    _fields_ = [
+        ("origin", C.c_double * 3),
+        ("lower_left", C.c_double * 3),
+        ("horizontal", C.c_double * 3),
+        ("vertical", C.c_double * 3),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+    ]
+
+
+class PtObject(C.Structure):
+    _fields_ = [
+        ("shape_tag", C.c_uint32),
+        ("mat_tag", C.c_uint32),
+        ("shape", C.c_double * 9),
+        ("mat", C.c_double * 6),
+    ]
+
+
+class PtRenderParams(C.Structure):
+    _fields_ = [
+        ("spp", C.c_uint32),
+        ("spp_offset", C.c_uint32),
+        ("min_depth", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("integrator", C.c_uint32),
+        ("t_min", C.c_double),
+        ("band_rows", C.c_uint32),
+        ("band_index", C.c_uint32),
+        ("band_count", C.c_uint32),
+        ("max_paths_in_flight", C.c_uint64),
+        ("profile", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class PtStats(C.Structure):
+    _fields_ = [
+        ("samples", C.c_uint64),
+        ("vertices", C.c_uint64),
+        ("shadow_rays", C.c_uint64),
+        ("bounce_launches", C.c_uint32),
+        ("batches", C.c_uint32),
+        ("max_depth_reached", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("bounce_kernel_ms", C.c_double),
+        ("total_ms", C.c_double),
+    ]
+
+
+PT_SHAPE_SPHERE, PT_SHAPE_TRIANGLE = 0, 1
+PT_MAT_LAMBERT, PT_MAT_EMISSIVE, PT_MAT_MIRROR, PT_MAT_OREN_NAYAR = 0, 1, 2, 3
+PT_INTEGRATOR_MIS, PT_INTEGRATOR_BRDF_ONLY = 0, 1
+
+# every symbol include/pathtrace_amd.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    "pt_camera_new": (C.c_int, [_P(C.c_double), C.c_uint32, C.c_uint32, C.c_double, C.c_double, _P(PtCamera)]),
+    "pt_camera_look_at": (C.c_int, [_P(C.c_double), _P(C.c_double), _P(C.c_double), C.c_uint32, C.c_uint32,
+                                    C.c_double, _P(PtCamera)]),
+    "pt_default_params": (None, [_P(PtRenderParams)]),
+    "pt_tile_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_builtin_scene": (C.c_int, [C.c_uint32, C.c_uint32, _P(PtObject), C.c_uint32, _P(C.c_uint32)]),
+    "pt_context_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
+    "pt_context_destroy": (C.c_int, [C.c_void_p]),
+    "pt_context_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
+    "pt_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_sync": (C.c_int, [C.c_void_p]),
+    "pt_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
+    "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double,
+                                     _P(C.c_int32), _P(C.c_float)]),
+    "pt_last_error": (C.c_char_p, []),
+    "pt_abi_version": (C.c_uint32, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpathtrace_amd.so (built by `__graft_entry__.build()` / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP library first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no fallback path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pathtrace_amd error {code}: {msg}")
+        self.code = code
+
+
+def check(code):
+    if code != 0:
+        raise PtError(code, lib().pt_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,462 @@
+// pt_api.cpp -- C ABI (include/pathtrace_amd.h) and the wavefront driver.
+//
+// render() == everything src/main.rs:43-60 does: enumerate the tile's pixels, give
+// every pixel the RNG key (x, y) (main.rs:51), run SAMPLE_NUM paths per pixel
+// (world.rs:296) and fill the two film buffers (world.rs:55-57).  Here the pixel
+// x sample loop is a queue of paths in HBM advanced one vertex per kernel launch.
+//
+// There is no CPU fallback: without a HIP device every rendering entry point
+// fails with PT_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pathtrace_amd.h"
+#include "pt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                     \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return PT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return PT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr uint32_t kMaxBounces = 65536;        // depth lives in 16 bits of the path state
+constexpr uint32_t kBounceGroup = 8;           // launches enqueued between two queue-length read-backs
+constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
+constexpr uint32_t kMaxGrid = 256 * 8;         // 256 CUs x 8 workgroups of 256 threads
+
+}  // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // scene
+    DevBuf<float4> scan, shape, mat;
+    DevBuf<ptk::Run> runs;
+    DevBuf<uint32_t> lights;
+    ptk::SceneView view{};
+    bool has_scene = false;
+    // wavefront state
+    DevBuf<float4> queue[2][4];
+    DevBuf<float4> lsamp;
+    DevBuf<uint32_t> counters;
+    DevBuf<unsigned long long> dstats;
+    DevBuf<uint32_t> rows;
+    DevBuf<double> film;
+    uint32_t* h_counters = nullptr;   // pinned
+    unsigned long long* h_dstats = nullptr;
+    std::vector<uint32_t> rows_host;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    PtStats stats{};
+    bool stats_pending = false;
+};
+
+namespace {
+
+int ensure_events(PtContext* c, size_t n) {
+    while (c->ev_pool.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    return PT_OK;
+}
+
+std::vector<uint32_t> tile_row_list(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count) {
+    std::vector<uint32_t> rows;
+    if (band_rows == 0) band_rows = height ? height : 1;
+    if (band_count == 0) band_count = 1;
+    for (uint32_t y = 0; y < height; ++y)
+        if ((y / band_rows) % band_count == band_index) rows.push_back(y);
+    return rows;
+}
+
+float4 f4(double a, double b, double c, double d) { return make_float4((float)a, (float)b, (float)c, (float)d); }
+
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+uint32_t pt_abi_version(void) { return PT_ABI_VERSION; }
+
+void pt_default_params(PtRenderParams* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->spp = 3000;          // world.rs:18
+    p->spp_offset = 0;
+    p->min_depth = 4;       // rendering.rs:6
+    p->max_depth = 50;      // rendering.rs:7
+    p->integrator = PT_INTEGRATOR_MIS;   // Cargo.toml:7 default feature
+    p->t_min = 0.001;       // rendering.rs:41
+    p->band_rows = 0;
+    p->band_index = 0;
+    p->band_count = 1;
+    p->max_paths_in_flight = 0;
+    p->profile = 0;
+}
+
+uint32_t pt_tile_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count) {
+    return (uint32_t)tile_row_list(height, band_rows, band_index, band_count).size();
+}
+
+int pt_context_create(int device, PtContext** out) {
+    if (!out) return fail(PT_ERR_INVALID_ARG, "pt_context_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PT_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(PT_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    PtContext* c = new PtContext();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "hipStreamCreateWithFlags failed");
+    }
+    c->stream = c->own_stream;
+    if (hipHostMalloc((void**)&c->h_counters, (kMaxBounces + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_dstats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "context allocation failed");
+    }
+    *out = c;
+    return PT_OK;
+}
+
+int pt_context_destroy(PtContext* c) {
+    if (!c) return PT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->scan.release(); c->shape.release(); c->mat.release(); c->runs.release(); c->lights.release();
+    for (auto& q : c->queue) for (auto& b : q) b.release();
+    c->lsamp.release(); c->counters.release(); c->dstats.release(); c->rows.release(); c->film.release();
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_dstats) (void)hipHostFree(c->h_dstats);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PT_OK;
+}
+
+int pt_context_set_stream(PtContext* c, void* hip_stream) {
+    if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PT_OK;
+}
+
+// World::new's tail (world.rs:213-225) + flattening of Box<dyn Shape>/Box<dyn Material>.
+int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
+    if (!c || (!objs && n)) return fail(PT_ERR_INVALID_ARG, "pt_scene_upload: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float4> scan, shape(3 * (size_t)n + 1), mat(2 * (size_t)n + 1);
+    std::vector<ptk::Run> runs;
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < n; ++i) {
+        const PtObject& o = objs[i];
+        if (o.shape_tag > PT_SHAPE_TRIANGLE) return fail(PT_ERR_INVALID_ARG, "object %u: bad shape_tag %u", i, o.shape_tag);
+        if (o.mat_tag > PT_MAT_OREN_NAYAR) return fail(PT_ERR_INVALID_ARG, "object %u: bad mat_tag %u", i, o.mat_tag);
+        if (runs.empty() || runs.back().tag != o.shape_tag) {
+            ptk::Run r;
+            r.tag = o.shape_tag; r.first_obj = i; r.count = 0; r.off4 = (uint32_t)scan.size();
+            runs.push_back(r);
+        }
+        runs.back().count++;
+        if (o.shape_tag == PT_SHAPE_SPHERE) {
+            float4 s = f4(o.shape[0], o.shape[1], o.shape[2], o.shape[3]);
+            scan.push_back(s);
+            shape[3 * i] = s;
+            shape[3 * i + 1] = shape[3 * i + 2] = make_float4(0, 0, 0, 0);
+        } else {
+            float v0[3], v1[3], v2[3];
+            for (int k = 0; k < 3; ++k) { v0[k] = (float)o.shape[k]; v1[k] = (float)o.shape[3 + k]; v2[k] = (float)o.shape[6 + k]; }
+            float4 a0 = make_float4(v0[0], v0[1], v0[2], 0.f);
+            float4 a1 = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f);   // edge1, shape.rs:163
+            float4 a2 = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f);   // edge2, shape.rs:164
+            scan.push_back(a0); scan.push_back(a1); scan.push_back(a2);
+            shape[3 * i] = a0; shape[3 * i + 1] = a1; shape[3 * i + 2] = a2;
+        }
+        float p[6] = {(float)o.mat[0], (float)o.mat[1], (float)o.mat[2], (float)o.mat[3], (float)o.mat[4], (float)o.mat[5]};
+        uint32_t emits = 0;
+        if (o.mat_tag == PT_MAT_EMISSIVE) {
+            // emit().length() > 0 (world.rs:219-222), evaluated in f32
+            float l2 = std::fmaf(p[2], p[2], std::fmaf(p[1], p[1], p[0] * p[0]));
+            emits = std::sqrt(l2) > 0.0f ? 1u : 0u;
+        }
+        if (o.mat_tag == PT_MAT_OREN_NAYAR) {
+            float s2 = p[3] * p[3];                              // OrenNayar::new, material.rs:182-193
+            float A = 1.0f - 0.5f * s2 / (s2 + 0.33f);
+            float B = 0.45f * s2 / (s2 + 0.09f);
+            p[3] = A; p[4] = B; p[5] = 0.f;
+        }
+        uint32_t bits = o.mat_tag | (o.shape_tag << 8) | (emits << 16);
+        float fb;
+        std::memcpy(&fb, &bits, 4);
+        mat[2 * i] = make_float4(fb, p[0], p[1], p[2]);
+        mat[2 * i + 1] = make_float4(p[3], p[4], p[5], 0.f);
+        if (emits) lights.push_back(i);
+    }
+    int rc;
+    if ((rc = c->scan.ensure(scan.size() + 1))) return rc;
+    if ((rc = c->shape.ensure(shape.size()))) return rc;
+    if ((rc = c->mat.ensure(mat.size()))) return rc;
+    if ((rc = c->runs.ensure(runs.size() + 1))) return rc;
+    if ((rc = c->lights.ensure(lights.size() + 1))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the previous scene may still be in use
+    if (!scan.empty()) HIP_TRY(hipMemcpy(c->scan.p, scan.data(), scan.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->shape.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->mat.p, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!runs.empty()) HIP_TRY(hipMemcpy(c->runs.p, runs.data(), runs.size() * sizeof(ptk::Run), hipMemcpyHostToDevice));
+    if (!lights.empty()) HIP_TRY(hipMemcpy(c->lights.p, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->view.scan = c->scan.p; c->view.shape = c->shape.p; c->view.mat = c->mat.p;
+    c->view.runs = c->runs.p; c->view.lights = c->lights.p;
+    c->view.scan_f4 = (uint32_t)scan.size();
+    c->view.n_runs = (uint32_t)runs.size(); c->view.n_objs = n; c->view.n_lights = (uint32_t)lights.size();
+    c->has_scene = true;
+    return PT_OK;
+}
+
+int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* d_linear, uint8_t* d_rgba) {
+    if (!c || !cam || !prm || !d_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_device: null argument");
+    if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "pt_render_device: no scene uploaded");
+    if (cam->width < 2 || cam->height < 2)   // get_ray_with_offset divides by width-1 / height-1 (camera.rs:140-141)
+        return fail(PT_ERR_INVALID_ARG, "camera %ux%u: width and height must be >= 2", cam->width, cam->height);
+    if (prm->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
+    if (prm->integrator > PT_INTEGRATOR_BRDF_ONLY) return fail(PT_ERR_INVALID_ARG, "unknown integrator %u", prm->integrator);
+    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
+    if (prm->band_index >= band_count) return fail(PT_ERR_INVALID_ARG, "band_index %u >= band_count %u", prm->band_index, band_count);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+
+    std::vector<uint32_t> rows = tile_row_list(cam->height, prm->band_rows, prm->band_index, band_count);
+    const uint64_t np64 = (uint64_t)rows.size() * cam->width;
+    std::memset(&c->stats, 0, sizeof c->stats);
+    if (np64 == 0) return PT_OK;   // empty tile: nothing to render
+    uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : kDefaultMaxPaths;
+    if (cap > (1ull << 30)) cap = 1ull << 30;
+    if (np64 > cap)
+        return fail(PT_ERR_UNSUPPORTED, "tile of %llu pixels exceeds max_paths_in_flight %llu; use more bands",
+                    (unsigned long long)np64, (unsigned long long)cap);
+    const uint32_t np = (uint32_t)np64;
+    uint32_t nb_max = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(cap / np, 65535u), prm->spp);
+    if (nb_max == 0) nb_max = 1;
+    const size_t n_paths_max = (size_t)np * nb_max;
+    const uint32_t n_batches = (prm->spp + nb_max - 1) / nb_max;
+
+    int rc;
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 4; ++k)
+            if ((rc = c->queue[s][k].ensure(n_paths_max))) return rc;
+    if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
+    if ((rc = c->counters.ensure(kMaxBounces + 2))) return rc;
+    if ((rc = c->dstats.ensure(8))) return rc;
+    if ((rc = c->rows.ensure(rows.size()))) return rc;
+    if (n_batches > 1 && (rc = c->film.ensure((size_t)np * 3))) return rc;
+    if (rows != c->rows_host) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(c->rows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->rows_host = rows;
+    }
+
+    ptk::BounceArgs a{};
+    a.lsamp = c->lsamp.p;
+    a.counters = c->counters.p;
+    a.stats = c->dstats.p;
+    a.rows = c->rows.p;
+    a.sc = c->view;
+    for (int k = 0; k < 3; ++k) {
+        a.cam.origin[k] = (float)cam->origin[k]; a.cam.lower_left[k] = (float)cam->lower_left[k];
+        a.cam.horizontal[k] = (float)cam->horizontal[k]; a.cam.vertical[k] = (float)cam->vertical[k];
+    }
+    a.cam.width = cam->width; a.cam.height = cam->height;
+    a.np = np;
+    a.min_depth = prm->min_depth; a.max_depth = prm->max_depth;
+    a.t_min = (float)prm->t_min;
+    a.integrator = prm->integrator;
+
+    const bool profile = prm->profile != 0;
+    HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(c->ev_begin, st));
+    double bounce_ms = 0.0;
+    uint64_t vertices = 0;
+    uint32_t launches = 0, max_depth_reached = 0;
+
+    for (uint32_t batch = 0; batch < n_batches; ++batch) {
+        const uint32_t s0 = batch * nb_max;
+        const uint32_t nb = std::min(nb_max, prm->spp - s0);
+        const uint32_t n_first = np * nb;
+        a.n_first = n_first;
+        a.s_base = prm->spp_offset + s0;
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, (kMaxBounces + 2) * sizeof(uint32_t), st));
+        uint32_t b = 0;              // next bounce to launch
+        uint32_t upper = n_first;    // upper bound of the queue length entering bounce b
+        bool drained = false;
+        while (!drained) {
+            const uint32_t group_end = std::min(b + kBounceGroup, kMaxBounces);
+            const uint32_t group_begin = b;
+            if (profile && (rc = ensure_events(c, 2 * (size_t)(group_end - group_begin)))) return rc;
+            for (; b < group_end; ++b) {
+                a.bounce = b;
+                for (int k = 0; k < 4; ++k) {
+                    a.in.q[k] = c->queue[b & 1][k].p;
+                    a.out.q[k] = c->queue[(b + 1) & 1][k].p;
+                }
+                uint32_t grid = std::min<uint32_t>((upper + ptk::kBlock - 1) / ptk::kBlock, kMaxGrid);
+                if (grid == 0) grid = 1;
+                if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin)], st));
+                ptk::launch_bounce(a, b == 0, grid, st);
+                if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin) + 1], st));
+                ++launches;
+            }
+            HIP_TRY(hipGetLastError());
+            // queue lengths entering bounces group_begin+1 .. b
+            HIP_TRY(hipMemcpyAsync(c->h_counters + group_begin + 1, c->counters.p + group_begin + 1,
+                                   (b - group_begin) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (profile)
+                for (uint32_t k = 0; k < b - group_begin; ++k) {
+                    float ms = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[2 * k], c->ev_pool[2 * k + 1]));
+                    bounce_ms += ms;
+                }
+            c->h_counters[0] = n_first;
+            for (uint32_t k = group_begin; k < b; ++k) {
+                vertices += c->h_counters[k];
+                if (c->h_counters[k] > 0 && k > max_depth_reached) max_depth_reached = k;
+            }
+            upper = c->h_counters[b];
+            if (upper == 0 || b >= kMaxBounces) drained = true;
+        }
+        ptk::ResolveArgs r{};
+        r.lsamp = c->lsamp.p;
+        r.film = c->film.p;
+        r.out_linear = d_linear;
+        r.out_rgba = d_rgba;
+        r.np = np; r.nb = nb;
+        r.first_batch = batch == 0;
+        r.last_batch = batch + 1 == n_batches;
+        r.spp_total = prm->spp;
+        ptk::launch_resolve(r, st);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev_end, st));
+    HIP_TRY(hipMemcpyAsync(c->h_dstats, c->dstats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    c->stats.samples = (uint64_t)np * prm->spp;
+    c->stats.vertices = vertices;
+    c->stats.bounce_launches = launches;
+    c->stats.batches = n_batches;
+    c->stats.max_depth_reached = max_depth_reached;
+    c->stats.bounce_kernel_ms = bounce_ms;
+    c->stats_pending = true;
+    return PT_OK;
+}
+
+int pt_sync(PtContext* c) {
+    if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stats_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.total_ms = ms;
+        c->stats.shadow_rays = c->h_dstats[0];
+        c->stats_pending = false;
+    }
+    return PT_OK;
+}
+
+int pt_get_stats(PtContext* c, PtStats* out) {
+    if (!c || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    int rc = pt_sync(c);
+    if (rc) return rc;
+    *out = c->stats;
+    return PT_OK;
+}
+
+int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, int32_t* out_id,
+                       float* out_t) {
+    if (!c || !rays || !out_id || !out_t) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> r6(6 * (size_t)n);
+    for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];
+    float* d_r = nullptr; int32_t* d_id = nullptr; float* d_t = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_r, r6.size() * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&d_id, n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&d_t, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_r, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
+    ptk::launch_debug_hit(c->view, d_r, n, (float)t_min, (float)t_max, d_id, d_t, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_id, d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_r); (void)hipFree(d_id); (void)hipFree(d_t);
+    return PT_OK;
+}
+
+int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRenderParams* prm, float* out_linear,
+              uint8_t* out_rgba) {
+    if (!cam || !prm || !out_linear) return fail(PT_ERR_INVALID_ARG, "pt_render: null argument");
+    static std::mutex mu;
+    static PtContext* ctx = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    int rc;
+    if (!ctx && (rc = pt_context_create(0, &ctx))) return rc;
+    if ((rc = pt_scene_upload(ctx, objs, n))) return rc;
+    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
+    const size_t np = (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
+    if (np == 0) return PT_OK;
+    float* d_lin = nullptr; uint8_t* d_rgba = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_lin, np * 3 * sizeof(float)));
+    if (out_rgba) HIP_TRY(hipMalloc((void**)&d_rgba, np * 4));
+    rc = pt_render_device(ctx, cam, prm, d_lin, d_rgba);
+    if (!rc) rc = pt_sync(ctx);
+    if (!rc) {
+        HIP_TRY(hipMemcpy(out_linear, d_lin, np * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, d_rgba, np * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_lin);
+    if (d_rgba) (void)hipFree(d_rgba);
+    return rc;
+}
+
+}  // extern "C"

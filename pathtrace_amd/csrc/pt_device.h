@@ -1,0 +1,432 @@
+// pt_device.h -- device-side arithmetic of the wavefront path tracer (gfx950).
+//
+// FP32 restatement of the reference's per-vertex arithmetic (src/math.rs,
+// src/camera.rs, src/objects/*.rs).  The translation unit is compiled with
+// -ffp-contract=off: an FMA appears only where this file writes __builtin_fmaf
+// (dot, cross, a*s+b).  vector / scalar is vector * (1/scalar) with an IEEE
+// reciprocal; sin/cos(2*pi*u) is a fixed polynomial.  sqrtf and '/' are the
+// correctly-rounded forms (hipcc default), never -ffast-math: NaN ordering is
+// part of the reference's behaviour.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_DEV __device__ __forceinline__
+
+namespace ptd {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInf = __builtin_huge_valf();
+
+// ------------------------------------------------------------------ Vector3 (math.rs:3-244)
+struct f3 {
+    float x, y, z;
+};
+PT_DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }      // math.rs:139
+PT_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }      // math.rs:160
+PT_DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }         // math.rs:173
+PT_DEV f3 operator*(float s, f3 a) { return mk(a.x * s, a.y * s, a.z * s); }         // math.rs:186
+PT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }      // math.rs:195
+PT_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }                           // math.rs:234
+PT_DEV f3 operator/(f3 a, float s) { float inv = 1.0f / s; return mk(a.x * inv, a.y * inv, a.z * inv); }   // math.rs:208
+PT_DEV float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }     // math.rs:24
+PT_DEV float msub(float a, float b, float c, float d) { return __builtin_fmaf(a, b, -(c * d)); }
+PT_DEV f3 cross(f3 a, f3 b) {                                                        // math.rs:29
+    return mk(msub(a.y, b.z, a.z, b.y), msub(a.z, b.x, a.x, b.z), msub(a.x, b.y, a.y, b.x));
+}
+PT_DEV float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }                     // math.rs:38
+PT_DEV f3 normalize(f3 a) { float len = length(a); return len > 0.0f ? a / len : a; }   // math.rs:48-51
+PT_DEV float luminance(f3 a) { return 0.2126f * a.x + 0.7152f * a.y + 0.0722f * a.z; }  // math.rs:133
+PT_DEV bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+PT_DEV f3 madd(f3 a, float s, f3 b) {                                                // a*s + b
+    return mk(__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z));
+}
+// tangent*x + bitangent*y + normal*z (material.rs:121)
+PT_DEV f3 frame3(f3 t, float x, f3 b, float y, f3 n, float z) { return madd(n, z, madd(b, y, t * x)); }
+PT_DEV bool finite3(f3 v) { return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z); }
+
+// sin/cos(2*pi*u), u in (0,1): quadrant reduction on u, cephes sinf/cosf kernels.
+PT_DEV void sincos2pi(float u, float& s, float& c) {
+    float k = __builtin_rintf(u * 4.0f);
+    float r = __builtin_fmaf(k, -0.25f, u);
+    float t = r * 6.28318530717958647692f;
+    float z = t * t;
+    float sp = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float st = __builtin_fmaf(sp * z, t, t);
+    float cp = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                              4.166664568298827e-2f);
+    float ct = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    int q = ((int)k) & 3;
+    float ss = (q & 1) ? ct : st;
+    float cc = (q & 1) ? st : ct;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q == 2 || q == 3) ss = -ss;
+    s = ss; c = cc;
+}
+
+// ------------------------------------------------------------------ counter RNG
+// Philox4x32-10 (Random123).  key = (x, y) = the two words of the reference's
+// per-pixel seed (y<<32)|x (src/main.rs:51); ctr = (sample, depth, block, 0).
+PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+enum { BLK_LIGHT = 0, BLK_BSDF = 1 };
+constexpr uint32_t kDepthCamera = 0xFFFFFFFFu;
+// 23-bit uniform on the open interval (0,1): (2k+1)/2^24, exact in f32.
+PT_DEV float u01(uint32_t r) { return (float)(((r >> 9) << 1) | 1u) * (1.0f / 16777216.0f); }
+
+// ------------------------------------------------------------------ scene records
+// shape record, 3 float4 per object:
+//   sphere   : r0 = (cx, cy, cz, radius)
+//   triangle : r0 = (v0, -), r1 = (e1 = v1-v0, -), r2 = (e2 = v2-v0, -)
+// material record, 2 float4 per object:
+//   m0 = (mat_tag | shape_tag<<8 | emits<<16 as bits, p0, p1, p2), m1 = (p3, p4, p5, -)
+//   lambert/emissive: p0..2 = colour; mirror: p0 = roughness, p1..3 = colour, p4 = metallic, p5 = ior;
+//   oren-nayar: p0..2 = albedo, p3 = A, p4 = B (material.rs:182-193)
+enum { SHAPE_SPHERE = 0, SHAPE_TRIANGLE = 1 };
+enum { MAT_LAMBERT = 0, MAT_EMISSIVE = 1, MAT_MIRROR = 2, MAT_OREN_NAYAR = 3 };
+
+struct Mat {
+    uint32_t tag, shape_tag, emits;
+    f3 color;
+    float roughness, metallic, ior, on_a, on_b;
+};
+PT_DEV Mat load_mat(const float4* __restrict__ mat, int id) {
+    float4 m0 = mat[2 * id], m1 = mat[2 * id + 1];
+    uint32_t bits = __float_as_uint(m0.x);
+    Mat m;
+    m.tag = bits & 0xFF; m.shape_tag = (bits >> 8) & 0xFF; m.emits = (bits >> 16) & 1;
+    m.roughness = 0.0f; m.metallic = 0.0f; m.ior = 1.0f; m.on_a = 1.0f; m.on_b = 0.0f;
+    if (m.tag == MAT_MIRROR) {
+        m.roughness = m0.y; m.color = mk(m0.z, m0.w, m1.x); m.metallic = m1.y; m.ior = m1.z;
+    } else {
+        m.color = mk(m0.y, m0.z, m0.w);
+        m.on_a = m1.x; m.on_b = m1.y;
+    }
+    return m;
+}
+
+struct Hit {       // HitRecord, base.rs:6-15
+    f3 point, normal;
+    float t;
+    bool front_face;
+};
+// HitRecord::new, base.rs:19-33
+PT_DEV void face_forward(Hit& h, f3 outward, f3 dir) {
+    h.front_face = dot(dir, outward) < 0.0f;
+    h.normal = h.front_face ? outward : -outward;
+}
+
+// Tail of SphereShape::hit / TriangleShape::hit for the winning object of the
+// scan (shape.rs:84-88, 194-197): point, outward normal, face-forwarding.
+PT_DEV Hit finish_hit(const float4* __restrict__ shape, int id, uint32_t shape_tag, f3 o, f3 d, float t) {
+    Hit h;
+    h.t = t;
+    h.point = madd(d, t, o);                                    // ray.at(t), camera.rs:18-20
+    f3 outward;
+    float4 r0 = shape[3 * id];
+    if (shape_tag == SHAPE_SPHERE) {
+        outward = (h.point - mk(r0.x, r0.y, r0.z)) / r0.w;      // shape.rs:86
+    } else {
+        float4 r1 = shape[3 * id + 1], r2 = shape[3 * id + 2];
+        outward = normalize(cross(mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z)));   // shape.rs:195
+    }
+    face_forward(h, outward, d);
+    return h;
+}
+
+// ------------------------------------------------------------------ shape sampling (shape.rs)
+// SphereShape::sample_surface_from_point, shape.rs:91-145.  with_target: the MIS
+// look-ahead form (point given, no draws).
+PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float r1, float r2, f3& point,
+                          float& pdf_omega) {
+    f3 center = mk(r0.x, r0.y, r0.z);
+    float radius = r0.w;
+    f3 to_center = center - from;
+    float distance_sq = dot(to_center, to_center);
+    float sin_theta_max_sq = (radius * radius) / distance_sq;
+    float cos_theta_max = __builtin_sqrtf(__builtin_fmaxf(1.0f - sin_theta_max_sq, 0.0f));
+    float solid_angle = 2.0f * kPi * (1.0f - cos_theta_max);
+    pdf_omega = 1.0f / solid_angle;
+    if (with_target) { point = target; return; }
+    float cos_theta = 1.0f - r1 + r1 * cos_theta_max;
+    float sin_theta = __builtin_sqrtf(__builtin_fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    float sphi, cphi;
+    sincos2pi(r2, sphi, cphi);
+    f3 w = normalize(to_center);
+    f3 up = __builtin_fabsf(w.y) > 0.999f ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
+    f3 u = normalize(cross(up, w));
+    f3 v = cross(w, u);
+    f3 direction = frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta);
+    f3 rd = normalize(direction);                       // Ray::new normalises (camera.rs:13)
+    f3 oc = from - center;
+    float a = dot(direction, direction);                // un-normalised direction, shape.rs:131-132
+    float half_b = dot(oc, direction);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = __builtin_fmaf(half_b, half_b, -(a * c));
+    // deliberate deviation: disc clamped at 0 (reference: unguarded sqrt, shape.rs:136)
+    float t = (-half_b - __builtin_sqrtf(__builtin_fmaxf(disc, 0.0f))) * (1.0f / a);
+    point = madd(rd, t, from);
+}
+// TriangleShape::sample_surface_from_point, shape.rs:200-242
+PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 target, float r1, float r2,
+                            f3& point, float& pdf_omega) {
+    if (with_target) {
+        point = target;
+    } else {
+        float sqrt_r1 = __builtin_sqrtf(r1);
+        float u = 1.0f - sqrt_r1;
+        float v = r2 * sqrt_r1;
+        point = madd(e2, v, madd(e1, u, v0));
+    }
+    f3 cr = cross(e1, e2);
+    f3 normal = normalize(cr);
+    float area = length(cr) * 0.5f;
+    f3 to_light = point - from;
+    float d = length(to_light);
+    f3 light_dir = to_light / d;
+    float cos_light = __builtin_fabsf(dot(normal, -light_dir));
+    float pdf_area = 1.0f / area;
+    pdf_omega = cos_light > 1e-8f ? pdf_area * (d * d) / cos_light : 1e-8f;
+}
+PT_DEV void shape_sample(const float4* __restrict__ shape, int id, uint32_t shape_tag, f3 from, bool with_target,
+                         f3 target, float r1, float r2, f3& point, float& pdf_omega) {
+    float4 r0 = shape[3 * id];
+    if (shape_tag == SHAPE_SPHERE) {
+        sphere_sample(r0, from, with_target, target, r1, r2, point, pdf_omega);
+    } else {
+        float4 q1 = shape[3 * id + 1], q2 = shape[3 * id + 2];
+        triangle_sample(mk(r0.x, r0.y, r0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), from, with_target, target,
+                        r1, r2, point, pdf_omega);
+    }
+}
+
+// ------------------------------------------------------------------ materials
+// local frame: material.rs:112-119, mirror.rs:21-27
+PT_DEV void frame_of(f3 n, f3& tangent, f3& bitangent) {
+    f3 up = __builtin_fabsf(n.y) > 0.999f ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
+    tangent = normalize(cross(up, n));
+    bitangent = cross(n, tangent);
+}
+// cosine-weighted direction: material.rs:93-122 / :267-295
+PT_DEV f3 cosine_sample(f3 n, float r1, float r2) {
+    float sphi, cphi;
+    sincos2pi(r1, sphi, cphi);
+    float cos_theta = __builtin_sqrtf(r2);
+    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    float x = sin_theta * cphi, y = sin_theta * sphi, z = cos_theta;
+    f3 t, b;
+    frame_of(n, t, b);
+    return normalize(frame3(t, x, b, y, n, z));
+}
+PT_DEV float powi5(float x) { float x2 = x * x; return x2 * x2 * x; }
+
+// ---- Mirror (mirror.rs)
+PT_DEV f3 mirror_f(const Mat& m, float cos_theta) {                        // mirror.rs:126-132
+    float f0d = (1.0f - m.ior) / (1.0f + m.ior);
+    f0d = f0d * f0d;
+    f3 f0 = mk(f0d, f0d, f0d) * (1.0f - m.metallic) + m.color * m.metallic;
+    return f0 + (mk(1.0f, 1.0f, 1.0f) - f0) * powi5(1.0f - cos_theta);
+}
+PT_DEV float mirror_g1(const Mat& m, float cos_theta) {                    // mirror.rs:136-149
+    if (cos_theta <= 0.0f) return 0.0f;
+    float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
+    float cos2 = cos_theta * cos_theta;
+    float term = alpha2 + (1.0f - alpha2) * cos2;
+    return 2.0f * cos_theta / (cos_theta + __builtin_sqrtf(term));
+}
+PT_DEV float mirror_lambda(float alpha2, float c) {                        // mirror.rs:165-172
+    float c2 = c * c;
+    float num = __builtin_sqrtf(alpha2 + (1.0f - alpha2) * c2);
+    return (num - c) / (2.0f * c);
+}
+PT_DEV float mirror_g(const Mat& m, float ci, float co) {                  // mirror.rs:153-175
+    if (ci <= 0.0f || co <= 0.0f) return 0.0f;
+    float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
+    return 1.0f / (1.0f + mirror_lambda(alpha2, ci) + mirror_lambda(alpha2, co));
+}
+PT_DEV float ggx_d(float alpha2, float n_h) {                              // mirror.rs:69-70
+    float denom = (n_h * n_h) * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (kPi * denom * denom);
+}
+// Mirror::brdf, mirror.rs:62-88
+PT_DEV void mirror_brdf(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) {
+    f3 i = -dir_in;
+    float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
+    f3 h = normalize(i + o);
+    float n_h = dot(n, h);
+    float d = ggx_d(alpha2, n_h);
+    float i_n = __builtin_fmaxf(dot(n, i), 0.0f);
+    float o_n = __builtin_fmaxf(dot(n, o), 0.0f);
+    float g = mirror_g(m, i_n, o_n);
+    float cos_theta = __builtin_fmaxf(dot(i, h), 0.0f);
+    f3 fr = mirror_f(m, cos_theta);
+    float denom_brdf = 4.0f * i_n * o_n;
+    f = d * g * fr / denom_brdf;
+    float i_h = __builtin_fabsf(dot(i, h));
+    pdf = d * __builtin_fabsf(n_h) / (4.0f * i_h);
+}
+// Mirror::btdf, mirror.rs:90-124
+PT_DEV void mirror_btdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, float& pdf) {
+    f3 i = -dir_in;
+    f3 h = -(normalize(i * eta + o));
+    float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
+    float n_h = dot(n, h);
+    float d = ggx_d(alpha2, n_h);
+    float i_n = __builtin_fabsf(dot(n, i));
+    float o_n = __builtin_fabsf(dot(n, o));
+    float g = mirror_g(m, i_n, o_n);
+    float i_h = dot(i, h), o_h = dot(o, h);
+    float cos_theta = __builtin_fabsf(i_h);
+    float denom_term = eta * i_h + o_h;
+    f3 fr = mirror_f(m, cos_theta);
+    f = (mk(1.0f, 1.0f, 1.0f) - fr) * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
+        (i_n * o_n * denom_term * denom_term);
+    float jac = __builtin_fabsf(o_h) / (denom_term * denom_term);
+    pdf = d * __builtin_fabsf(n_h) * jac;
+}
+// Mirror::sample_ggx_vndf, mirror.rs:17-60
+PT_DEV f3 mirror_vndf(const Mat& m, f3 view, f3 n, float r1, float r2) {
+    float alpha = m.roughness * m.roughness;
+    f3 tangent, bitangent;
+    frame_of(n, tangent, bitangent);
+    f3 vl = mk(dot(view, tangent), dot(view, bitangent), dot(view, n));
+    f3 vh = normalize(mk(alpha * vl.x, alpha * vl.y, vl.z));
+    float lensq = vh.x * vh.x + vh.y * vh.y;
+    f3 t1 = lensq > 0.0f ? mk(-vh.y, vh.x, 0.0f) * (1.0f / __builtin_sqrtf(lensq)) : mk(1.0f, 0.0f, 0.0f);
+    f3 t2 = cross(vh, t1);
+    float r = __builtin_sqrtf(r1);
+    float sphi, cphi;
+    sincos2pi(r2, sphi, cphi);
+    float p1 = r * cphi;
+    float p2 = r * sphi;
+    float s = 0.5f * (1.0f + vh.z);
+    p2 = (1.0f - s) * __builtin_sqrtf(1.0f - p1 * p1) + s * p2;
+    float p3 = __builtin_sqrtf(__builtin_fmaxf(1.0f - p1 * p1 - p2 * p2, 0.0f));
+    f3 nh = frame3(t1, p1, t2, p2, vh, p3);
+    f3 ne = normalize(mk(alpha * nh.x, alpha * nh.y, __builtin_fmaxf(nh.z, 0.0f)));
+    return normalize(frame3(tangent, ne.x, bitangent, ne.y, n, ne.z));
+}
+// Mirror::bsdf_pdf_sample, mirror.rs:200-305
+PT_DEV void mirror_sample(const Mat& m, f3 dir_in, float eta, f3 n, float r1, float r2, float u_lobe, f3& wo, f3& f,
+                          float& pdf, float& cos_out) {
+    f3 i = -dir_in;
+    float i_dot_n = dot(i, n);
+    f3 h = mirror_vndf(m, i, n, r1, r2);
+    float i_h = dot(i, h);
+    wo = n; f = mk(0.0f, 0.0f, 0.0f); pdf = 1.0f; cos_out = 0.0f;      // the failure tuple (mirror.rs:216)
+    if (i_h <= 0.0f) return;
+    f3 fr = mirror_f(m, i_h);
+    float sin2_i = 1.0f - i_h * i_h;
+    float cos2_t = 1.0f - (eta * eta) * sin2_i;
+    bool tir = cos2_t < 0.0f;
+    float rr_f = fr.x;
+    if (tir || m.metallic > 0.99f) { rr_f = 1.0f; fr = mk(1.0f, 1.0f, 1.0f); }
+    bool is_reflect = u_lobe < rr_f;
+    float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
+    float n_h = dot(n, h);
+    float d = ggx_d(alpha2, n_h);
+    if (is_reflect) {
+        f3 o = 2.0f * i_h * h - i;
+        f3 on = normalize(o);
+        float o_n = __builtin_fmaxf(dot(n, on), 0.0f);
+        float i_n = __builtin_fmaxf(i_dot_n, 0.0f);
+        float g = mirror_g(m, i_n, o_n);
+        float denom_brdf = 4.0f * i_n * o_n;
+        f3 brdf = fr * d * g / (denom_brdf * rr_f);
+        float g1v = mirror_g1(m, i_n);
+        float pdf_vndf = g1v * d * __builtin_fmaxf(i_h, 0.0f) / i_n;
+        float p = pdf_vndf / (4.0f * __builtin_fabsf(i_h));
+        if (!finite3(brdf) || !__builtin_isfinite(p) || p <= 0.0f) return;
+        wo = on; f = brdf; pdf = p; cos_out = o_n;
+    } else {
+        float cos_t = __builtin_sqrtf(cos2_t);
+        f3 o = h * (eta * i_h - cos_t) - i * eta;
+        f3 on = normalize(o);
+        float o_h = dot(on, h);
+        float o_n = __builtin_fabsf(dot(n, on));
+        float i_n = __builtin_fabsf(i_dot_n);
+        float denom_term = eta * i_h + o_h;
+        float g = mirror_g(m, i_n, o_n);
+        f3 one_f = mk(1.0f, 1.0f, 1.0f) - fr;
+        f3 btdf = one_f * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
+                  (i_n * o_n * denom_term * denom_term * (1.0f - rr_f));
+        float jac = __builtin_fabsf(o_h) / (denom_term * denom_term);
+        float g1v = mirror_g1(m, i_n);
+        float pdf_vndf = g1v * d * __builtin_fmaxf(i_h, 0.0f) / i_n;
+        float p = pdf_vndf * jac;
+        if (!finite3(btdf) || !__builtin_isfinite(p) || p <= 0.0f) return;
+        wo = on; f = btdf; pdf = p; cos_out = o_n;
+    }
+}
+// OrenNayar::bsdf_pdf, material.rs:221-265 (atan2f/cosf are libdevice: the one
+// material whose f32 result is not bit-reproducible on the host)
+PT_DEV void oren_nayar_eval(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) {
+    f3 i = -dir_in;
+    float ci = __builtin_fmaxf(dot(i, n), 0.0f), co = __builtin_fmaxf(dot(o, n), 0.0f);
+    float si = __builtin_sqrtf(__builtin_fmaxf(1.0f - ci * ci, 0.0f));
+    float so = __builtin_sqrtf(__builtin_fmaxf(1.0f - co * co, 0.0f));
+    f3 tangent, bitangent;
+    frame_of(n, tangent, bitangent);
+    float phi_i = atan2f(dot(i, bitangent), dot(i, tangent));
+    float phi_o = atan2f(dot(o, bitangent), dot(o, tangent));
+    float cos_phi = __builtin_fmaxf(cosf(phi_i - phi_o), 0.0f);
+    float sin_alpha, tan_beta;
+    if (ci > co) { tan_beta = ci > 1e-6f ? si / ci : 0.0f; sin_alpha = so; }
+    else { tan_beta = co > 1e-6f ? so / co : 0.0f; sin_alpha = si; }
+    float term = m.on_a + m.on_b * cos_phi * sin_alpha * tan_beta;
+    f = m.color * (term / kPi);
+    pdf = __builtin_fmaxf(dot(o, n), 0.0f) / kPi;
+}
+// Object::bsdf_pdf (object.rs:35-43)
+PT_DEV void bsdf_pdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, float& pdf) {
+    if (m.tag == MAT_LAMBERT) {                                      // material.rs:86-91
+        f = m.color / kPi;
+        pdf = __builtin_fmaxf(dot(o, n), 0.0f) / kPi;
+    } else if (m.tag == MAT_EMISSIVE) {                              // material.rs:139-148
+        f = mk(0.0f, 0.0f, 0.0f); pdf = 1.0f;
+    } else if (m.tag == MAT_MIRROR) {                                // mirror.rs:179-198
+        f3 i = -dir_in;
+        float i_n = dot(i, n), o_n = dot(o, n);
+        bool is_refl = i_n * o_n > 0.0f;
+        if (m.metallic > 0.99f && !is_refl) { f = mk(0.0f, 0.0f, 0.0f); pdf = 1.0f; }
+        else if (is_refl) mirror_brdf(m, dir_in, o, n, f, pdf);
+        else mirror_btdf(m, dir_in, eta, o, n, f, pdf);
+    } else {
+        oren_nayar_eval(m, dir_in, o, n, f, pdf);
+    }
+}
+// Object::bsdf_pdf_sample (object.rs:46-54); d4 = the vertex's BLK_BSDF block
+PT_DEV void bsdf_pdf_sample(const Mat& m, f3 dir_in, float eta, f3 n, const uint32_t d4[4], f3& wo, f3& f,
+                            float& pdf, float& cos_out) {
+    float r1 = u01(d4[0]), r2 = u01(d4[1]);
+    if (m.tag == MAT_MIRROR) {
+        mirror_sample(m, dir_in, eta, n, r1, r2, u01(d4[2]), wo, f, pdf, cos_out);
+        return;
+    }
+    wo = (m.tag == MAT_EMISSIVE) ? n : cosine_sample(n, r1, r2);     // material.rs:150-158 / :93-122
+    bsdf_pdf(m, dir_in, eta, wo, n, f, pdf);                         // default impl material.rs:29-40
+    cos_out = __builtin_fmaxf(dot(wo, n), 0.0f);
+}
+
+// Russian-roulette probability, rendering.rs:91-98
+PT_DEV float rr_prob(uint32_t depth, uint32_t min_depth, uint32_t max_depth, f3 next_tp) {
+    if (depth < min_depth) return 1.0f;
+    float l = __builtin_fminf(luminance(next_tp), 1.0f);
+    if (depth >= max_depth) return l * __builtin_ldexpf(1.0f, -(int)(depth - min_depth));
+    return l;
+}
+
+}  // namespace ptd

@@ -1,0 +1,83 @@
+// pt_kernels.h -- launch interface between the host driver (pt_api.cpp) and the
+// HIP kernels (pt_kernels.hip).  Plain structs, no HIP types besides float4 and
+// hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptk {
+
+// One contiguous run of same-shape objects of World.objects, in object order
+// (the order decides closest-hit ties, src/world.rs:281-287).
+struct Run {
+    uint32_t tag;        // SHAPE_SPHERE / SHAPE_TRIANGLE
+    uint32_t first_obj;  // object index of the run's first primitive
+    uint32_t count;      // primitives in the run
+    uint32_t off4;       // offset of the run in the scan array, in float4 units
+};
+
+struct SceneView {
+    const float4* scan;      // scan records, run-packed: sphere = 1 float4 (c, r); triangle = 3 float4 (v0, e1, e2)
+    const float4* shape;     // 3 float4 per object (gather form), see pt_device.h
+    const float4* mat;       // 2 float4 per object
+    const Run* runs;
+    const uint32_t* lights;  // object indices of the emitters (world.rs:214-225)
+    uint32_t scan_f4;        // float4 count of `scan`
+    uint32_t n_runs, n_objs, n_lights;
+};
+
+struct CameraF {             // Camera's cached fields in f32 (camera.rs:36-38)
+    float origin[3], lower_left[3], horizontal[3], vertical[3];
+    uint32_t width, height;
+};
+
+// Path-state queue: 4 float4 planes, index = queue slot (coalesced 16 B/lane).
+//   q0 = (o.x, o.y, o.z, d.x)  q1 = (d.y, d.z, beta.x, beta.y)
+//   q2 = (beta.z, L.x, L.y, L.z)  q3 = (pdf_prev, eta_in, bits(pid), bits(s_local<<16 | depth))
+struct Queue {
+    float4* q[4];
+};
+
+struct BounceArgs {
+    Queue in, out;
+    float4* lsamp;            // per-path final radiance, index = pid
+    uint32_t* counters;       // counters[b] = paths entering bounce b
+    unsigned long long* stats;  // [0] shadow rays
+    const uint32_t* rows;     // tile-local row -> image row
+    SceneView sc;
+    CameraF cam;
+    uint32_t bounce;          // b
+    uint32_t n_first;         // paths of the batch (bounce 0 only)
+    uint32_t np;              // pixels of the tile
+    uint32_t s_base;          // sample index of s_local = 0 (spp_offset + batch start)
+    uint32_t min_depth, max_depth;
+    float t_min;
+    uint32_t integrator;
+};
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kSmallSceneF4 = 1024;   // scenes whose scan array is <= 16 KiB stay whole in LDS
+constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tiles otherwise (divisible by 3: whole triangles)
+
+// grid = number of 256-thread workgroups (the kernels grid-stride over the queue)
+void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
+
+// Film: sum the nb samples of every tile pixel in sample order into the f64
+// accumulator (world.rs:311), and on the last batch write mean, sqrt-gamma and
+// truncated RGBA8 (world.rs:315-332).
+struct ResolveArgs {
+    const float4* lsamp;
+    double* film;             // np*3 doubles (may be null when the render is a single batch)
+    float* out_linear;        // np*3
+    uint8_t* out_rgba;        // np*4 or null
+    uint32_t np, nb;
+    uint32_t first_batch, last_batch;
+    uint32_t spp_total;
+};
+void launch_resolve(const ResolveArgs& a, hipStream_t st);
+
+// World::hit_scene on arbitrary rays (debug/parity entry).
+void launch_debug_hit(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max, int32_t* out_id,
+                      float* out_t, hipStream_t st);
+
+}  // namespace ptk

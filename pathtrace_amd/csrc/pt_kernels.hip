@@ -1,0 +1,369 @@
+// pt_kernels.hip -- HIP kernels of the wavefront path tracer, gfx950 (wave64).
+//
+// One launch of k_bounce advances every queued path by ONE vertex of
+// MisStrategy::ray_color / BrdfOnlyStrategy::ray_color (src/rendering.rs:34-142,
+// 214-265) in the iterative order of SURVEY 3.5:
+//     closest hit of the path ray            World::hit_scene      world.rs:270-290
+//     miss -> retire; emitter -> credit (MIS look-ahead weight), retire
+//     NEE: pick light, sample its surface    World::sample_light_point  world.rs:251-267
+//          shadow scan, BSDF eval, MIS weight                      rendering.rs:55-81
+//     BSDF sample, throughput, Russian roulette                    rendering.rs:83-102
+//     survivors are compacted into the output queue (wave64 ballot + prefix popcount,
+//     one atomicAdd per wave); retired paths store their radiance to lsamp[pid].
+// Bounce 0 generates the camera ray itself (Camera::get_ray_with_offset,
+// camera.rs:139-147; jitter draws world.rs:299) instead of reading the queue.
+//
+// Data layout: path state = 4 float4 planes (SoA of float4 -> every lane moves
+// 16 B per instruction, 1 KiB per wave-instruction); scene primitives are staged
+// in LDS and read by all 64 lanes at the same address (broadcast, conflict-free).
+// The grid is persistent (grid-stride over the queue) and reads the queue length
+// from device memory, so no host round-trip sits between bounces.
+#include "pt_device.h"
+#include "pt_kernels.h"
+
+using namespace ptd;
+
+namespace ptk {
+
+// ------------------------------------------------------------------ primitive tests
+// SphereShape::hit (shape.rs:53-82) against the running closest t.
+PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min, float& closest, int& id, int obj) {
+    f3 oc = o - mk(s.x, s.y, s.z);
+    float half_b = dot(oc, d);
+    float c = dot(oc, oc) - s.w * s.w;
+    float disc = __builtin_fmaf(half_b, half_b, -(a * c));
+    if (disc < 0.0f) return;                       // NaN falls through, as in the reference (Q10)
+    float sqrtd = __builtin_sqrtf(disc);
+    float root = (-half_b - sqrtd) * inv_a;
+    if (root < t_min || closest < root) {
+        root = (-half_b + sqrtd) * inv_a;
+        if (root < t_min || closest < root) return;
+    }
+    closest = root;
+    id = obj;
+}
+// TriangleShape::hit (shape.rs:161-192), Moeller-Trumbore; e1, e2 precomputed.
+PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
+    f3 h = cross(d, e2);
+    float a = dot(e1, h);
+    if (__builtin_fabsf(a) < 1e-8f) return;
+    float f = 1.0f / a;
+    f3 s = o - v0;
+    float u = f * dot(s, h);
+    if (!(u >= 0.0f && u <= 1.0f)) return;         // RangeInclusive::contains: NaN rejected
+    f3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = f * dot(e2, q);
+    if (t < t_min || t > closest) return;
+    closest = t;
+    id = obj;
+}
+
+PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float a,
+                     float inv_a, float t_min, float& closest, int& id) {
+    if (tag == SHAPE_SPHERE) {
+        for (uint32_t i = 0; i < n; ++i) sphere_test(p[i], o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
+    } else {
+        for (uint32_t i = 0; i < n; ++i) {
+            float4 a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
+            triangle_test(mk(a0.x, a0.y, a0.z), mk(a1.x, a1.y, a1.z), mk(a2.x, a2.y, a2.z), o, d, t_min, closest, id,
+                          first_obj + (int)i);
+        }
+    }
+}
+
+// World::hit_scene (world.rs:270-290): linear scan in object order with a
+// shrinking t_max.  SMALL: the whole scan array already sits in LDS.  Otherwise
+// every run is streamed through one LDS tile; the loop is block-uniform (all
+// threads of the workgroup call this together, active or not).
+template <bool SMALL>
+PT_DEV void scan_closest(const SceneView& sc, float4* lds, f3 o, f3 d, float t_min, float t_max, int& id_out,
+                         float& t_out) {
+    float a = dot(d, d);
+    float inv_a = 1.0f / a;
+    float closest = t_max;
+    int id = -1;
+    for (uint32_t r = 0; r < sc.n_runs; ++r) {
+        Run run = sc.runs[r];
+        const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
+        if (SMALL) {
+            scan_run(lds + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
+        } else {
+            const uint32_t tile_prims = kTileF4 / per;
+            for (uint32_t p0 = 0; p0 < run.count; p0 += tile_prims) {
+                uint32_t np = run.count - p0 < tile_prims ? run.count - p0 : tile_prims;
+                __syncthreads();
+                const float4* src = sc.scan + run.off4 + p0 * per;
+                for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) lds[k] = src[k];
+                __syncthreads();
+                scan_run(lds, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
+            }
+        }
+    }
+    id_out = id;
+    t_out = closest;
+}
+
+// ------------------------------------------------------------------ bounce kernel
+template <bool FIRST, bool SMALL, bool MIS>
+__global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
+    extern __shared__ float4 lds[];
+    if (SMALL) {
+        for (uint32_t k = threadIdx.x; k < a.sc.scan_f4; k += kBlock) lds[k] = a.sc.scan[k];
+        __syncthreads();
+    }
+    const uint32_t n_in = FIRST ? a.n_first : a.counters[a.bounce];
+    const uint32_t lane = threadIdx.x & 63u;
+    const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+    uint32_t wave_shadow = 0;
+
+    for (uint32_t base = blockIdx.x * kBlock; base < n_in; base += gridDim.x * kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n_in;
+
+        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f), beta = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
+        float pdf_prev = 0.0f, eta_in = 1.0f;
+        uint32_t pid = 0, s_local = 0, depth = 0, px = 0, py = 0;
+
+        if (active) {
+            if (FIRST) {
+                pid = i;
+                s_local = i / a.np;
+            } else {
+                float4 q0 = a.in.q[0][i], q1 = a.in.q[1][i], q2 = a.in.q[2][i], q3 = a.in.q[3][i];
+                o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y);
+                beta = mk(q1.z, q1.w, q2.x); L = mk(q2.y, q2.z, q2.w);
+                pdf_prev = q3.x; eta_in = q3.y;
+                pid = __float_as_uint(q3.z);
+                uint32_t sd = __float_as_uint(q3.w);
+                s_local = sd >> 16; depth = sd & 0xFFFFu;
+            }
+            // pixel of the path: key of its RNG stream = (x, y), main.rs:51
+            uint32_t pix = pid - s_local * a.np;
+            uint32_t yl = pix / a.cam.width;
+            px = pix - yl * a.cam.width;
+            py = a.rows[yl];
+        }
+        const uint32_t sample = a.s_base + s_local;
+
+        if (FIRST && active) {
+            uint32_t dc[4];
+            philox4x32_10(sample, kDepthCamera, 0u, 0u, px, py, dc);
+            float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
+            float u = ((float)px + ox) / (float)(a.cam.width - 1u);               // camera.rs:140
+            float v = ((float)(a.cam.height - 1u - py) + oy) / (float)(a.cam.height - 1u);   // world.rs:299 y flip
+            f3 dir = mk(a.cam.lower_left[0], a.cam.lower_left[1], a.cam.lower_left[2]) +
+                     mk(a.cam.horizontal[0], a.cam.horizontal[1], a.cam.horizontal[2]) * u +
+                     mk(a.cam.vertical[0], a.cam.vertical[1], a.cam.vertical[2]) * v - cam_o;   // camera.rs:143-144
+            o = cam_o;
+            d = normalize(dir);                                                   // Ray::new, camera.rs:13
+        }
+
+        // ---- scan #1: closest hit of the path ray (rendering.rs:41)
+        int id; float t;
+        scan_closest<SMALL>(a.sc, lds, o, d, a.t_min, kInf, id, t);
+        bool alive = active && id >= 0;
+
+        Hit hit;
+        Mat m;
+        hit.point = o; hit.normal = d; hit.t = 0.0f; hit.front_face = false;
+        m.tag = MAT_LAMBERT; m.shape_tag = 0; m.emits = 0; m.color = mk(0.f, 0.f, 0.f);
+        m.roughness = 0.f; m.metallic = 0.f; m.ior = 1.f; m.on_a = 1.f; m.on_b = 0.f;
+        if (alive) {
+            m = load_mat(a.sc.mat, id);
+            hit = finish_hit(a.sc.shape, id, m.shape_tag, o, d, t);
+            if (m.emits) {
+                if (!MIS || depth == 0u) {
+                    L = L + beta * m.color;                                       // rendering.rs:44-45 / :225-227
+                } else {
+                    // emitter reached by a BSDF-sampled ray: MIS weight against the light
+                    // pdf seen from the previous vertex = this ray's origin (rendering.rs:107-121)
+                    f3 sp; float pdf_shape;
+                    shape_sample(a.sc.shape, id, m.shape_tag, o, true, hit.point, 0.f, 0.f, sp, pdf_shape);
+                    float w_bsdf = pdf_prev / (pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
+                    L = L + beta * m.color * w_bsdf;
+                }
+                alive = false;
+            }
+        }
+
+        // ---- NEE: light pick + surface sample (world.rs:251-267)
+        bool need_shadow = false;
+        f3 light_dir = mk(0.f, 0.f, 0.f), ls_emission = mk(0.f, 0.f, 0.f);
+        float distance = 0.0f, ls_pdf = 1.0f;
+        if (MIS && alive && a.sc.n_lights > 0u) {
+            uint32_t dl[4];
+            philox4x32_10(sample, depth, BLK_LIGHT, 0u, px, py, dl);
+            uint32_t li = __umulhi(dl[0], a.sc.n_lights);                         // random_range(0..n), world.rs:255
+            int lobj = (int)a.sc.lights[li];
+            Mat lm = load_mat(a.sc.mat, lobj);
+            f3 lp; float pdf_shape;
+            shape_sample(a.sc.shape, lobj, lm.shape_tag, hit.point, false, hit.point, u01(dl[1]), u01(dl[2]), lp,
+                         pdf_shape);
+            ls_emission = lm.color;                                               // world.rs:259
+            ls_pdf = pdf_shape / (float)a.sc.n_lights;                            // world.rs:260
+            f3 to_light = lp - hit.point;                                         // rendering.rs:58-60
+            distance = length(to_light);
+            light_dir = normalize(to_light);
+            need_shadow = true;
+        }
+
+        // ---- scan #2: visibility (rendering.rs:62-65); skipped when no lane needs it
+        bool visible = false;
+        if (MIS) {
+            bool any_shadow = SMALL ? (__ballot(need_shadow) != 0ull) : (__syncthreads_or(need_shadow) != 0);
+            if (any_shadow) {
+                f3 sdir = need_shadow ? normalize(light_dir) : mk(0.f, 0.f, 0.f);   // Ray::new normalises again
+                f3 sorg = need_shadow ? hit.point : mk(0.f, 0.f, 0.f);
+                int sid; float st;
+                scan_closest<SMALL>(a.sc, lds, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
+                visible = need_shadow && sid < 0;
+                wave_shadow += (uint32_t)__popcll(__ballot(need_shadow));
+            }
+        }
+        f3 direct = mk(0.f, 0.f, 0.f);
+        if (visible) {
+            float cos_theta = __builtin_fabsf(dot(hit.normal, light_dir));        // rendering.rs:68
+            f3 bsdf; float pdf_bsdf;
+            bsdf_pdf(m, d, eta_in, light_dir, hit.normal, bsdf, pdf_bsdf);        // :71-72 (stale eta, Q5)
+            float w_nee = ls_pdf / (ls_pdf + pdf_bsdf);                           // :73
+            direct = w_nee * bsdf * ls_emission * cos_theta / ls_pdf;             // :75-76
+        }
+
+        // ---- BSDF sample, throughput, Russian roulette (rendering.rs:83-102)
+        if (alive) {
+            uint32_t db[4];
+            philox4x32_10(sample, depth, BLK_BSDF, 0u, px, py, db);
+            float eta_mat = m.tag == MAT_MIRROR ? m.ior : 1.0f;                   // get_eta, material.rs:50 / mirror.rs:317
+            float eta_here = hit.front_face ? 1.0f / eta_mat : eta_mat;           // rendering.rs:20-25
+            f3 wo, bsdf; float pdf, cos_theta;
+            bsdf_pdf_sample(m, d, eta_here, hit.normal, db, wo, bsdf, pdf, cos_theta);   // :84-85
+            f3 next_tp = beta * bsdf * cos_theta / pdf;                           // :89
+            float rr = rr_prob(depth, a.min_depth, a.max_depth, next_tp);         // :91-98
+            if (u01(db[3]) > rr) {                                                // :100-102 (drops direct, Q1)
+                alive = false;
+            } else {
+                L = L + beta * direct;
+                beta = next_tp / rr;                                              // :129
+                if (is_zero(beta) || depth >= 65534u) {                           // Q7: nothing downstream contributes
+                    alive = false;
+                } else {
+                    pdf_prev = pdf;
+                    o = hit.point;
+                    d = normalize(wo);                                            // Ray::new, :86
+                    eta_in = eta_here;                                            // :87
+                    depth += 1u;
+                }
+            }
+        }
+
+        // ---- retire or compact
+        if (active && !alive) a.lsamp[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+        unsigned long long mask = __ballot(alive);
+        if (mask != 0ull) {
+            uint32_t cnt = (uint32_t)__popcll(mask);
+            uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t wbase = 0;
+            if (lane == 0u) wbase = atomicAdd(&a.counters[a.bounce + 1u], cnt);
+            wbase = __shfl(wbase, 0);
+            if (alive) {
+                uint32_t j = wbase + rank;
+                a.out.q[0][j] = make_float4(o.x, o.y, o.z, d.x);
+                a.out.q[1][j] = make_float4(d.y, d.z, beta.x, beta.y);
+                a.out.q[2][j] = make_float4(beta.z, L.x, L.y, L.z);
+                a.out.q[3][j] = make_float4(pdf_prev, eta_in, __uint_as_float(pid),
+                                            __uint_as_float((s_local << 16) | depth));
+            }
+        }
+    }
+    if (MIS && lane == 0u && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
+}
+
+template <bool FIRST, bool SMALL, bool MIS>
+static void launch_bounce_t(const BounceArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    hipLaunchKernelGGL((k_bounce<FIRST, SMALL, MIS>), dim3(grid), dim3(kBlock), lds_bytes, st, a);
+}
+
+void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st) {
+    const bool small = a.sc.scan_f4 <= kSmallSceneF4;
+    const bool mis = a.integrator == 0;
+    const size_t lds = (small ? (a.sc.scan_f4 ? a.sc.scan_f4 : 1u) : kTileF4) * sizeof(float4);
+#define PT_CASE(F, S, M) \
+    if (first == F && small == S && mis == M) { launch_bounce_t<F, S, M>(a, grid, lds, st); return; }
+    PT_CASE(true, true, true) PT_CASE(true, true, false) PT_CASE(true, false, true) PT_CASE(true, false, false)
+    PT_CASE(false, true, true) PT_CASE(false, true, false) PT_CASE(false, false, true) PT_CASE(false, false, false)
+#undef PT_CASE
+}
+
+// ------------------------------------------------------------------ film resolve
+// World::render_pixel's tail (world.rs:311-332).  One thread per tile pixel; the
+// nb samples of the batch are added in sample order into an f64 sum, so the film
+// does not depend on how paths were scheduled.
+__global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.np) return;
+    double r = 0.0, g = 0.0, b = 0.0;
+    if (!a.first_batch) { r = a.film[3 * (size_t)p]; g = a.film[3 * (size_t)p + 1]; b = a.film[3 * (size_t)p + 2]; }
+    for (uint32_t s = 0; s < a.nb; ++s) {
+        float4 v = a.lsamp[(size_t)s * a.np + p];
+        r += (double)v.x; g += (double)v.y; b += (double)v.z;                     // world.rs:311
+    }
+    if (!a.last_batch) {
+        a.film[3 * (size_t)p] = r; a.film[3 * (size_t)p + 1] = g; a.film[3 * (size_t)p + 2] = b;
+        return;
+    }
+    double c[3] = {r / (double)a.spp_total, g / (double)a.spp_total, b / (double)a.spp_total};   // world.rs:315
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a.out_linear[3 * (size_t)p + k] = (float)c[k];                            // luminance_data, world.rs:318-319
+        if (a.out_rgba) {
+            double gm = __builtin_sqrt(c[k]);                                     // gamma 2.0, world.rs:322-324
+            double cl = gm < 0.0 ? 0.0 : (gm > 1.0 ? 1.0 : gm);                   // clamp keeps NaN
+            double q = cl * 255.0;
+            a.out_rgba[4 * (size_t)p + k] = (q != q) ? (uint8_t)0 : (uint8_t)q;   // `as u8`: truncation, NaN -> 0
+        }
+    }
+    if (a.out_rgba) a.out_rgba[4 * (size_t)p + 3] = 255;                          // world.rs:331
+}
+void launch_resolve(const ResolveArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3((a.np + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
+}
+
+// ------------------------------------------------------------------ debug: hit_scene on arbitrary rays
+template <bool SMALL>
+__global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView sc, const float* __restrict__ rays6, uint32_t n,
+                                                      float t_min, float t_max, int32_t* out_id, float* out_t) {
+    extern __shared__ float4 lds[];
+    if (SMALL) {
+        for (uint32_t k = threadIdx.x; k < sc.scan_f4; k += kBlock) lds[k] = sc.scan[k];
+        __syncthreads();
+    }
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        bool active = i < n;
+        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
+        if (active) {
+            o = mk(rays6[6 * (size_t)i], rays6[6 * (size_t)i + 1], rays6[6 * (size_t)i + 2]);
+            d = normalize(mk(rays6[6 * (size_t)i + 3], rays6[6 * (size_t)i + 4], rays6[6 * (size_t)i + 5]));
+        }
+        int id; float t;
+        scan_closest<SMALL>(sc, lds, o, d, t_min, t_max, id, t);
+        if (active) { out_id[i] = id; out_t[i] = id >= 0 ? t : 0.0f; }
+    }
+}
+void launch_debug_hit(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max, int32_t* out_id,
+                      float* out_t, hipStream_t st) {
+    const bool small = sc.scan_f4 <= kSmallSceneF4;
+    uint32_t grid = (n + kBlock - 1) / kBlock;
+    if (grid > 2048u) grid = 2048u;
+    if (grid == 0u) grid = 1u;
+    if (small)
+        hipLaunchKernelGGL(k_debug_hit<true>, dim3(grid), dim3(kBlock), (sc.scan_f4 ? sc.scan_f4 : 1u) * sizeof(float4),
+                           st, sc, rays6, n, t_min, t_max, out_id, out_t);
+    else
+        hipLaunchKernelGGL(k_debug_hit<false>, dim3(grid), dim3(kBlock), kTileF4 * sizeof(float4), st, sc, rays6, n,
+                           t_min, t_max, out_id, out_t);
+}
+
+}  // namespace ptk
