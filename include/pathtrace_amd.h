@@ -95,7 +95,10 @@ typedef struct {
      * (0 = library default).                                                  */
     uint64_t max_paths_in_flight;
     uint32_t profile;        /* 1: time every bounce launch with HIP events    */
-    uint32_t reserved;
+    /* Workgroups (256 threads) of the persistent bounce grid; every wave owns one
+     * private queue segment.  0 = library default (4 per CU).  Results do not
+     * depend on it.                                                           */
+    uint32_t workgroups;
 } PtRenderParams;
 
 /* Counters of the last render on a context. */

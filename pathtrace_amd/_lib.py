@@ -44,7 +44,7 @@ class PtRenderParams(C.Structure):
         ("band_count", C.c_uint32),
         ("max_paths_in_flight", C.c_uint64),
         ("profile", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("workgroups", C.c_uint32),
     ]
 
 

@@ -55,7 +55,8 @@ template <class T> struct DevBuf {
 constexpr uint32_t kMaxBounces = 65536;        // depth lives in 16 bits of the path state
 constexpr uint32_t kBounceGroup = 8;           // launches enqueued between two queue-length read-backs
 constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
-constexpr uint32_t kMaxGrid = 256 * 8;         // 256 CUs x 8 workgroups of 256 threads
+constexpr uint32_t kDefaultGrid = 256 * 4;     // 256 CUs x 4 resident workgroups (k_bounce: 4 waves/SIMD)
+constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
 
 }  // namespace
 
@@ -70,9 +71,9 @@ struct PtContext {
     ptk::SceneView view{};
     bool has_scene = false;
     // wavefront state
-    DevBuf<float4> queue[2][4];
+    DevBuf<float4> queue[4];
     DevBuf<float4> lsamp;
-    DevBuf<uint32_t> counters;
+    DevBuf<uint32_t> counters, seg_count;
     DevBuf<unsigned long long> dstats;
     DevBuf<uint32_t> rows;
     DevBuf<double> film;
@@ -151,7 +152,7 @@ int pt_context_create(int device, PtContext** out) {
         return fail(PT_ERR_HIP, "hipStreamCreateWithFlags failed");
     }
     c->stream = c->own_stream;
-    if (hipHostMalloc((void**)&c->h_counters, (kMaxBounces + 2) * sizeof(uint32_t)) != hipSuccess ||
+    if (hipHostMalloc((void**)&c->h_counters, (size_t)(kMaxBounces + 2) * ptk::kCounterShards * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_dstats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
         delete c;
@@ -166,8 +167,8 @@ int pt_context_destroy(PtContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->runs.release(); c->lights.release();
-    for (auto& q : c->queue) for (auto& b : q) b.release();
-    c->lsamp.release(); c->counters.release(); c->dstats.release(); c->rows.release(); c->film.release();
+    for (auto& b : c->queue) b.release();
+    c->lsamp.release(); c->counters.release(); c->seg_count.release(); c->dstats.release(); c->rows.release(); c->film.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_dstats) (void)hipHostFree(c->h_dstats);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -282,12 +283,24 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const size_t n_paths_max = (size_t)np * nb_max;
     const uint32_t n_batches = (prm->spp + nb_max - 1) / nb_max;
 
+    // Queue segments: one per wave of the (fixed) bounce grid; bounce 0 deals 64-path
+    // chunks round-robin, so a segment holds at most ceil(chunks / waves) chunks.
+    const uint32_t grid_env = prm->workgroups;
+    const uint32_t chunks_max = (uint32_t)((n_paths_max + 63) / 64);
+    uint32_t grid = grid_env ? grid_env : kDefaultGrid;
+    grid = std::min<uint32_t>(grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (grid == 0) grid = 1;
+    const uint32_t nw = grid * kWavesPerBlock;
+    const uint32_t seg_cap = ((chunks_max + nw - 1) / nw) * 64u;
+    const size_t q_slots = (size_t)nw * seg_cap;
+    const size_t n_counter = (size_t)(kMaxBounces + 2) * ptk::kCounterShards;
+
     int rc;
-    for (int s = 0; s < 2; ++s)
-        for (int k = 0; k < 4; ++k)
-            if ((rc = c->queue[s][k].ensure(n_paths_max))) return rc;
+    for (int k = 0; k < 4; ++k)
+        if ((rc = c->queue[k].ensure(q_slots))) return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
-    if ((rc = c->counters.ensure(kMaxBounces + 2))) return rc;
+    if ((rc = c->counters.ensure(n_counter))) return rc;
+    if ((rc = c->seg_count.ensure(nw))) return rc;
     if ((rc = c->dstats.ensure(8))) return rc;
     if ((rc = c->rows.ensure(rows.size()))) return rc;
     if (n_batches > 1 && (rc = c->film.ensure((size_t)np * 3))) return rc;
@@ -298,6 +311,9 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     }
 
     ptk::BounceArgs a{};
+    for (int k = 0; k < 4; ++k) a.q.q[k] = c->queue[k].p;
+    a.seg_count = c->seg_count.p;
+    a.seg_cap = seg_cap;
     a.lsamp = c->lsamp.p;
     a.counters = c->counters.p;
     a.stats = c->dstats.p;
@@ -326,31 +342,28 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         const uint32_t n_first = np * nb;
         a.n_first = n_first;
         a.s_base = prm->spp_offset + s0;
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, (kMaxBounces + 2) * sizeof(uint32_t), st));
         uint32_t b = 0;              // next bounce to launch
-        uint32_t upper = n_first;    // upper bound of the queue length entering bounce b
+        uint64_t entering = n_first; // paths entering bounce b
         bool drained = false;
         while (!drained) {
             const uint32_t group_end = std::min(b + kBounceGroup, kMaxBounces);
             const uint32_t group_begin = b;
+            // totals of the bounces this group feeds: rows group_begin+1 .. group_end
+            HIP_TRY(hipMemsetAsync(c->counters.p + (size_t)(group_begin + 1) * ptk::kCounterShards, 0,
+                                   (size_t)(group_end - group_begin) * ptk::kCounterShards * sizeof(uint32_t), st));
             if (profile && (rc = ensure_events(c, 2 * (size_t)(group_end - group_begin)))) return rc;
             for (; b < group_end; ++b) {
                 a.bounce = b;
-                for (int k = 0; k < 4; ++k) {
-                    a.in.q[k] = c->queue[b & 1][k].p;
-                    a.out.q[k] = c->queue[(b + 1) & 1][k].p;
-                }
-                uint32_t grid = std::min<uint32_t>((upper + ptk::kBlock - 1) / ptk::kBlock, kMaxGrid);
-                if (grid == 0) grid = 1;
                 if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin)], st));
                 ptk::launch_bounce(a, b == 0, grid, st);
                 if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin) + 1], st));
                 ++launches;
             }
             HIP_TRY(hipGetLastError());
-            // queue lengths entering bounces group_begin+1 .. b
-            HIP_TRY(hipMemcpyAsync(c->h_counters + group_begin + 1, c->counters.p + group_begin + 1,
-                                   (b - group_begin) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(c->h_counters + (size_t)(group_begin + 1) * ptk::kCounterShards,
+                                   c->counters.p + (size_t)(group_begin + 1) * ptk::kCounterShards,
+                                   (size_t)(b - group_begin) * ptk::kCounterShards * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (profile)
                 for (uint32_t k = 0; k < b - group_begin; ++k) {
@@ -358,13 +371,16 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
                     HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[2 * k], c->ev_pool[2 * k + 1]));
                     bounce_ms += ms;
                 }
-            c->h_counters[0] = n_first;
+            // paths entering bounce k: n_first for k = 0, else the sharded total written by bounce k-1
             for (uint32_t k = group_begin; k < b; ++k) {
-                vertices += c->h_counters[k];
-                if (c->h_counters[k] > 0 && k > max_depth_reached) max_depth_reached = k;
+                vertices += entering;
+                if (entering > 0 && k > max_depth_reached) max_depth_reached = k;
+                uint64_t next = 0;
+                for (uint32_t sh = 0; sh < ptk::kCounterShards; ++sh)
+                    next += c->h_counters[(size_t)(k + 1) * ptk::kCounterShards + sh];
+                entering = next;
             }
-            upper = c->h_counters[b];
-            if (upper == 0 || b >= kMaxBounces) drained = true;
+            if (entering == 0 || b >= kMaxBounces) drained = true;
         }
         ptk::ResolveArgs r{};
         r.lsamp = c->lsamp.p;

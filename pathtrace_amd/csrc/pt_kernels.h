@@ -38,10 +38,14 @@ struct Queue {
     float4* q[4];
 };
 
+constexpr uint32_t kCounterShards = 16;
+
 struct BounceArgs {
-    Queue in, out;
+    Queue q;                  // compacted in place, one private segment per wave
+    uint32_t* seg_count;      // [wave] queued paths of the wave's segment (in: this bounce, out: next)
+    uint32_t seg_cap;         // slots per segment (multiple of 64)
     float4* lsamp;            // per-path final radiance, index = pid
-    uint32_t* counters;       // counters[b] = paths entering bounce b
+    uint32_t* counters;       // counters[b*kCounterShards + s]: sharded total of paths entering bounce b
     unsigned long long* stats;  // [0] shadow rays
     const uint32_t* rows;     // tile-local row -> image row
     SceneView sc;
@@ -59,7 +63,8 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kSmallSceneF4 = 1024;   // scenes whose scan array is <= 16 KiB stay whole in LDS
 constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tiles otherwise (divisible by 3: whole triangles)
 
-// grid = number of 256-thread workgroups (the kernels grid-stride over the queue)
+// grid = number of 256-thread workgroups; it fixes the number of queue segments
+// (4 per workgroup) and must not change between the bounces of one batch
 void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
 
 // Film: sum the nb samples of every tile pixel in sample order into the f64
