@@ -255,3 +255,32 @@ extern "C" uint32_t orc_tile_rows(uint32_t height, uint32_t band_rows, uint32_t 
     return (uint32_t)tile_rows(height, band_rows, band_index, band_count).size();
 }
 
+
+// Debug: per-vertex records of one camera sample in the iterative form.
+// rec (24 doubles per vertex): depth, obj, t, point3, normal3, beta3, [12] ls.pdf | pdf_prev,
+// [13] visible | pdf_shape, [14] w_nee | w_bsdf, [15] pdf_bsdf, [16] light distance, [17] direct.x,
+// [18] bsdf sample pdf, [19] rr, [20] u_rr, [21..23] L so far.  Returns the number of vertices.
+extern "C" int orc_trace_path(const PtCamera* pc, const PtObject* objs, uint32_t n, const PtRenderParams* pp,
+                              int precision, uint32_t x, uint32_t y, uint32_t sample, double* rec, int max_vertices) {
+    Trace tr;
+    Counters cn;
+    Params prm = make_params(pp);
+    Draws dr{{x, y}, sample};
+    uint32_t dc[4];
+    dr.block(DEPTH_CAMERA, 0, dc);
+    if (precision == 64) {
+        Scene<double> sc = build_scene<double>(objs, n);
+        Camera<double> cam = make_camera<double>(pc);
+        Ray<double> ray = cam.get_ray_with_offset(x, cam.height - 1 - y, u01(dc[0]), u01(dc[1]));
+        ray_color_iter<double>(sc, prm, ray, dr, cn, &tr);
+    } else {
+        Scene<float> sc = build_scene<float>(objs, n);
+        Camera<float> cam = make_camera<float>(pc);
+        Ray<float> ray = cam.get_ray_with_offset(x, cam.height - 1 - y, (float)u01(dc[0]), (float)u01(dc[1]));
+        ray_color_iter<float>(sc, prm, ray, dr, cn, &tr);
+    }
+    int nv = (int)(tr.rec.size() / 24);
+    int m = nv < max_vertices ? nv : max_vertices;
+    std::memcpy(rec, tr.rec.data(), (size_t)m * 24 * sizeof(double));
+    return nv;
+}

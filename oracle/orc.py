@@ -118,3 +118,11 @@ def vec3(op, a, b=None, c=None, s=0.0, precision=F64):
     out = np.zeros(3, dtype=np.float64)
     ret = lib().orc_vec3(C.c_int(precision), C.c_int(op), _p(A), _p(B), _p(Cc), C.c_double(s), _p(out))
     return ret, out
+
+
+def trace_path(cam, objs, params, x, y, sample, precision=F64, max_vertices=128):
+    """Per-vertex records (24 doubles, layout in oracle_capi.cpp) of one camera sample, iterative form."""
+    rec = np.zeros((max_vertices, 24), dtype=np.float64)
+    n = lib().orc_trace_path(C.byref(cam), objs, C.c_uint32(len(objs)), C.byref(params), C.c_int(precision),
+                             C.c_uint32(x), C.c_uint32(y), C.c_uint32(sample), _p(rec), C.c_int(max_vertices))
+    return rec[: min(n, max_vertices)]

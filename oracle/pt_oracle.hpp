@@ -339,8 +339,18 @@ template <class R> inline bool sphere_hit(const Obj<R>& s, const Ray<R>& ray, R 
     V3<R> oc = ray.origin - s.center;
     R a = ray.direction.dot(ray.direction);
     R half_b = oc.dot(ray.direction);
-    R c = oc.dot(oc) - s.radius * s.radius;
-    R disc = Ar<R>::kFloat ? Ar<R>::mad(half_b, half_b, -(a * c)) : half_b * half_b - a * c;
+    R disc;
+    if (Ar<R>::kFloat) {
+        // f32 mode: half_b^2 - a*c cancels catastrophically for a small sphere far from the
+        // origin (abs error ~|oc|^2 * 2^-24 against r^2).  Algebraically identical, robust form
+        // (Haines et al., Ray Tracing Gems ch. 7): disc = a * (r^2 - |oc - (half_b/a) d|^2).
+        R k = half_b * (R(1) / a);
+        V3<R> l = madd(ray.direction, -k, oc);
+        disc = a * (s.radius * s.radius - l.dot(l));
+    } else {
+        R c = oc.dot(oc) - s.radius * s.radius;
+        disc = half_b * half_b - a * c;
+    }
     if (disc < 0) return false;
     R sqrtd = std::sqrt(disc);
     R root = Ar<R>::rcp_div(-half_b - sqrtd, a);
@@ -390,13 +400,24 @@ inline void sphere_sample(const Obj<R>& s, const Hit<R>& from, const Hit<R>* tar
     R distance_sq = to_center.dot(to_center);
     R sin_theta_max_sq = (s.radius * s.radius) / distance_sq;
     R cos_theta_max = std::sqrt(std::fmax(R(1) - sin_theta_max_sq, R(0)));
-    R solid_angle = R(2) * kPi<R>() * (R(1) - cos_theta_max);
+    // f32 mode: 1 - cos_theta_max = 1 - sqrt(1 - s) loses all its digits for a small or distant
+    // light (s = r^2/d^2 ~ 1e-5 against ulp(1) = 6e-8); s / (1 + sqrt(1 - s)) is the same number.
+    R omc = Ar<R>::kFloat ? sin_theta_max_sq / (R(1) + cos_theta_max) : R(1) - cos_theta_max;
+    if (Ar<R>::kFloat && sin_theta_max_sq > R(1)) omc = R(1);   // observer inside: cos_theta_max = 0
+    R solid_angle = R(2) * kPi<R>() * omc;
     pdf_omega = R(1) / solid_angle;
     if (target) {
         point = target->point;
     } else {
-        R cos_theta = R(1) - r1 + r1 * cos_theta_max;
-        R sin_theta = std::sqrt(std::fmax(R(1) - cos_theta * cos_theta, R(0)));
+        R cos_theta, sin_theta;
+        if (Ar<R>::kFloat) {
+            R x = r1 * omc;                               // 1 - cos_theta
+            cos_theta = R(1) - x;
+            sin_theta = std::sqrt(std::fmax(x * (R(2) - x), R(0)));   // sqrt((1-c)(1+c))
+        } else {
+            cos_theta = R(1) - r1 + r1 * cos_theta_max;
+            sin_theta = std::sqrt(std::fmax(R(1) - cos_theta * cos_theta, R(0)));
+        }
         R sphi, cphi;
         Ar<R>::sincos2pi(r2, sphi, cphi);
         V3<R> w = to_center.normalize();
@@ -847,8 +868,13 @@ V3<R> ray_color_brdf_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32
 // form, so both forms visit identical vertices; only the order in which the
 // radiance terms are summed differs (sum(beta_k*D_k) vs nested Horner form).
 // A path whose next throughput is exactly (0,0,0) is retired.
+// Optional per-vertex trace of the iterative form (debugging aid for parity work):
+// 24 doubles per vertex, see orc_trace_path in oracle_capi.cpp.
+struct Trace { std::vector<double> rec; };
+
 template <class R>
-V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws& dr, Counters& cn) {
+V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws& dr, Counters& cn,
+                     Trace* tr = nullptr) {
     const R tmin = (R)p.t_min;
     const bool mis = p.integrator == PT_INTEGRATOR_MIS;
     V3<R> L = V3<R>::zero(), beta = V3<R>::one();
@@ -859,6 +885,15 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
         cn.scans++;
         cn.vertices++;
         if (depth > cn.max_depth) cn.max_depth = depth;
+        double* T = nullptr;
+        if (tr) {
+            tr->rec.resize(tr->rec.size() + 24, 0.0);
+            T = &tr->rec[tr->rec.size() - 24];
+            T[0] = depth; T[1] = oi; T[2] = oi >= 0 ? (double)hit.t : 0.0;
+            T[3] = hit.point.x; T[4] = hit.point.y; T[5] = hit.point.z;
+            T[6] = hit.normal.x; T[7] = hit.normal.y; T[8] = hit.normal.z;
+            T[9] = beta.x; T[10] = beta.y; T[11] = beta.z;
+        }
         if (oi < 0) break;
         const Obj<R>& obj = w.objs[oi];
         if (obj.emits) {
@@ -872,7 +907,9 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
                 shape_sample<R>(obj, from, &hit, R(0), R(0), sp, sn, pdf_shape, sd, dd);
                 R w_bsdf = pdf_prev / (pdf_prev + pdf_shape);
                 L += beta * le * w_bsdf;
+                if (T) { T[12] = pdf_prev; T[13] = pdf_shape; T[14] = w_bsdf; }
             }
+            if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
             break;
         }
         uint32_t dl[4], db[4];
@@ -894,7 +931,9 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
                     bsdf_pdf(obj, ray, light_dir, hit.normal, bsdf, pdf_bsdf);
                     R w_nee = ls.pdf / (ls.pdf + pdf_bsdf);
                     direct = w_nee * bsdf * ls.emission * cos_theta / ls.pdf;
+                    if (T) { T[14] = w_nee; T[15] = pdf_bsdf; }
                 }
+                if (T) { T[12] = ls.pdf; T[13] = visible ? 1.0 : 0.0; T[16] = distance; T[17] = direct.x; }
             }
         }
         dr.block(depth, BLK_BSDF, db);
@@ -904,8 +943,10 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
         bsdf_pdf_sample(obj, ray, hit.normal, db, wo, bsdf, pdf, cos_theta);
         V3<R> next_tp = beta * bsdf * cos_theta / pdf;
         R rr = rr_prob(p, depth, next_tp);
+        if (T) { T[18] = pdf; T[19] = rr; T[20] = (double)u01(db[3]); }
         if ((R)u01(db[3]) > rr) break;                   // drops `direct` too (Q1)
         L += beta * direct;
+        if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
         beta = next_tp / rr;
         if (beta.is_zero()) break;                       // Q7: nothing downstream can contribute
         if (depth >= 65534u) break;                      // device depth counter is 16 bits

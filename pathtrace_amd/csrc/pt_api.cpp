@@ -257,7 +257,7 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
 }
 
 int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* d_linear, uint8_t* d_rgba) {
-    if (!c || !cam || !prm || !d_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_device: null argument");
+    if (!c || !cam || !prm) return fail(PT_ERR_INVALID_ARG, "pt_render_device: null argument");
     if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "pt_render_device: no scene uploaded");
     if (cam->width < 2 || cam->height < 2)   // get_ray_with_offset divides by width-1 / height-1 (camera.rs:140-141)
         return fail(PT_ERR_INVALID_ARG, "camera %ux%u: width and height must be >= 2", cam->width, cam->height);
@@ -272,6 +272,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const uint64_t np64 = (uint64_t)rows.size() * cam->width;
     std::memset(&c->stats, 0, sizeof c->stats);
     if (np64 == 0) return PT_OK;   // empty tile: nothing to render
+    if (!d_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_device: d_linear_rgb is null");
     uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : kDefaultMaxPaths;
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)

@@ -158,11 +158,16 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
     float distance_sq = dot(to_center, to_center);
     float sin_theta_max_sq = (radius * radius) / distance_sq;
     float cos_theta_max = __builtin_sqrtf(__builtin_fmaxf(1.0f - sin_theta_max_sq, 0.0f));
-    float solid_angle = 2.0f * kPi * (1.0f - cos_theta_max);
+    // 1 - cos_theta_max = 1 - sqrt(1 - s) loses its digits in f32 for a small or distant light;
+    // s / (1 + sqrt(1 - s)) is the same number.  Observer inside the sphere: cos_theta_max = 0.
+    float omc = sin_theta_max_sq / (1.0f + cos_theta_max);
+    if (sin_theta_max_sq > 1.0f) omc = 1.0f;
+    float solid_angle = 2.0f * kPi * omc;
     pdf_omega = 1.0f / solid_angle;
     if (with_target) { point = target; return; }
-    float cos_theta = 1.0f - r1 + r1 * cos_theta_max;
-    float sin_theta = __builtin_sqrtf(__builtin_fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    float x1 = r1 * omc;                                   // 1 - cos_theta  (shape.rs:114)
+    float cos_theta = 1.0f - x1;
+    float sin_theta = __builtin_sqrtf(__builtin_fmaxf(x1 * (2.0f - x1), 0.0f));   // sqrt((1-c)(1+c))
     float sphi, cphi;
     sincos2pi(r2, sphi, cphi);
     f3 w = normalize(to_center);

@@ -30,8 +30,11 @@ namespace ptk {
 PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min, float& closest, int& id, int obj) {
     f3 oc = o - mk(s.x, s.y, s.z);
     float half_b = dot(oc, d);
-    float c = dot(oc, oc) - s.w * s.w;
-    float disc = __builtin_fmaf(half_b, half_b, -(a * c));
+    // half_b^2 - a*c cancels catastrophically in f32 for a small sphere far from the origin;
+    // same quantity, robust form: a * (r^2 - |oc - (half_b/a) d|^2)  (Ray Tracing Gems ch. 7)
+    float k = half_b * inv_a;
+    f3 l = madd(d, -k, oc);
+    float disc = a * (s.w * s.w - dot(l, l));
     if (disc < 0.0f) return;                       // NaN falls through, as in the reference (Q10)
     float sqrtd = __builtin_sqrtf(disc);
     float root = (-half_b - sqrtd) * inv_a;

@@ -1,0 +1,55 @@
+"""Multi-GPU: image tiles shard over ranks, one gather of the framebuffer.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" for the CPU tests).  Every pixel is an independent unit whose RNG key is a
+pure function of (x, y) (src/main.rs:51) and whose result lands in its own film
+slot (src/main.rs:58), so ranks render disjoint row bands with NO data-path
+collective; the only exchange is one gather of the finished tiles to rank 0.
+Bands are interleaved (rank g owns bands g, g+G, g+2G, ...) because the cost of a
+pixel depends on what it sees.  The result is bitwise independent of G.
+"""
+import torch
+import torch.distributed as dist
+
+from .api import tile_row_indices
+
+
+def default_band_rows(height, world_size, target_bands_per_rank=8):
+    """Band height giving every rank about `target_bands_per_rank` interleaved bands."""
+    return max(1, height // max(1, world_size * target_bands_per_rank))
+
+
+def gather_tiles(tile, height, band_rows, rank, world_size, group=None, dst=0):
+    """Gather per-rank tiles [rows_r, W, C] to `dst` and place their rows in image order.
+
+    One collective: dist.gather of equally padded tiles (row counts differ by at most
+    one band).  Returns the full [height, W, C] frame on `dst`, None elsewhere."""
+    rows = [tile_row_indices(height, band_rows, g, world_size) for g in range(world_size)]
+    max_rows = max(len(r) for r in rows)
+    assert tile.shape[0] == len(rows[rank]), (tile.shape, len(rows[rank]))
+    if world_size == 1:
+        frame = torch.empty((height,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+        frame[torch.as_tensor(rows[0], device=tile.device)] = tile
+        return frame
+    pad = torch.zeros((max_rows,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+    pad[: tile.shape[0]] = tile
+    bufs = [torch.empty_like(pad) for _ in range(world_size)] if rank == dst else None
+    dist.gather(pad, gather_list=bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    frame = torch.empty((height,) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+    for g in range(world_size):
+        if rows[g]:
+            frame[torch.as_tensor(rows[g], device=tile.device)] = bufs[g][: len(rows[g])]
+    return frame
+
+
+def render_distributed(ctx, cam, params, rank, world_size, band_rows=None, group=None, want_rgba=True):
+    """Render this rank's interleaved bands on its GPU and gather the frame(s) on rank 0."""
+    params.band_rows = band_rows or default_band_rows(cam.height, world_size)
+    params.band_index = rank
+    params.band_count = world_size
+    lin, rgba = ctx.render(cam, params, want_rgba=want_rgba)
+    frame = gather_tiles(lin, cam.height, params.band_rows, rank, world_size, group)
+    frame8 = gather_tiles(rgba, cam.height, params.band_rows, rank, world_size, group) if want_rgba else None
+    return frame, frame8

@@ -1,0 +1,62 @@
+"""N>1 path on CPU: world_size-2 gloo processes each produce their interleaved row
+bands (the oracle stands in for the GPU renderer here) and rank 0 gathers the
+frame with pathtrace_amd.dist.gather_tiles -- the same code path bench.py runs
+over RCCL.  The assembled frame must equal the single-process render bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, band_rows, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pathtrace_amd as pt
+    from pathtrace_amd.dist import gather_tiles
+    from oracle import orc
+    cam = pt.camera_new(width=W, height=H)
+    prm = pt.default_params(spp=2, band_rows=band_rows, band_index=rank, band_count=world)
+    lin, rgba, _ = orc.render(cam, pt.builtin_scene(1), prm, orc.F32, orc.ITERATIVE)
+    frame = gather_tiles(torch.from_numpy(lin.astype(np.float32)), H, band_rows, rank, world)
+    frame8 = gather_tiles(torch.from_numpy(rgba), H, band_rows, rank, world)
+    dist.barrier()
+    if rank == 0:
+        np.savez(out_path, lin=frame.numpy(), rgba=frame8.numpy())
+    else:
+        assert frame is None and frame8 is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,band_rows", [(22, 4), (16, 16), (9, 1)])
+def test_two_ranks_gather_equals_single_render(pt, orc, tmp_path, H, band_rows):
+    W = 20
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_worker, args=(2, _free_port(), H, W, band_rows, out), nprocs=2, join=True)
+    got = np.load(out)
+    cam = pt.camera_new(width=W, height=H)
+    full, full8, _ = orc.render(cam, pt.builtin_scene(1), pt.default_params(spp=2), orc.F32, orc.ITERATIVE)
+    assert np.array_equal(got["lin"], full.astype(np.float32))
+    assert np.array_equal(got["rgba"], full8)
+
+
+def test_gather_single_rank_reorders_nothing(pt):
+    from pathtrace_amd.dist import gather_tiles
+    t = torch.arange(5 * 3 * 2, dtype=torch.float32).reshape(5, 3, 2)
+    assert torch.equal(gather_tiles(t, 5, 2, 0, 1), t)

@@ -1,0 +1,104 @@
+"""Size-independent properties of the HIP path, checked at BASELINE.json's full
+sizes (1024x1024, 64 spp and the 10 000-sphere scene): determinism, invariance to
+how the work is scheduled (batches, queue segments, row bands), linearity in spp,
+consistency of the two film planes, closed-form radiometry."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(pt, ctx, cam, **kw):
+    lin, rgba = ctx.render(cam, pt.default_params(**kw))
+    return lin.cpu().numpy(), rgba.cpu().numpy(), ctx.stats()
+
+
+def test_full_size_c2_determinism_and_schedule_invariance(pt, gpu_ctx):
+    """1024^2 x 64 spp, scene C2: two runs are bitwise equal, and the film does not depend on the sample
+    batch size, the number of queue segments, or the row-band partition (1 / 2 / 8 tiles)."""
+    gpu_ctx.upload(pt.builtin_scene(2))
+    cam = pt.camera_new(width=1024, height=1024)
+    a, a8, sa = _render(pt, gpu_ctx, cam, spp=64)
+    b, b8, sb = _render(pt, gpu_ctx, cam, spp=64)
+    assert np.array_equal(a, b) and np.array_equal(a8, b8) and sa.vertices == sb.vertices
+    assert sa.samples == 1024 * 1024 * 64 and sa.batches == 1
+    assert np.isfinite(a).all() and a.min() >= 0.0
+    c, c8, sc = _render(pt, gpu_ctx, cam, spp=64, max_paths_in_flight=5 * 1024 * 1024)     # 13 ragged batches
+    assert sc.batches == 13 and np.array_equal(a, c) and np.array_equal(a8, c8) and sc.vertices == sa.vertices
+    d, d8, sd = _render(pt, gpu_ctx, cam, spp=64, workgroups=333)
+    assert np.array_equal(a, d) and np.array_equal(a8, d8) and sd.vertices == sa.vertices
+    for G, band in [(2, 64), (8, 16)]:
+        frame = np.zeros_like(a)
+        verts = 0
+        for g in range(G):
+            t, _, st = _render(pt, gpu_ctx, cam, spp=64, band_rows=band, band_index=g, band_count=G)
+            frame[pt.tile_row_indices(1024, band, g, G)] = t
+            verts += st.vertices
+        assert np.array_equal(frame, a) and verts == sa.vertices
+    # V/S for this scene (reported in DESIGN.md): forced 4 bounces, early exits on the light / open front
+    assert 4.0 < sa.vertices / sa.samples < 6.0
+
+
+def test_full_size_spp_linearity(pt, gpu_ctx):
+    """The film is a mean over samples: halves rendered with spp_offset average to the whole."""
+    gpu_ctx.upload(pt.builtin_scene(2))
+    cam = pt.camera_new(width=1024, height=1024)
+    full, _, _ = _render(pt, gpu_ctx, cam, spp=64)
+    lo, _, _ = _render(pt, gpu_ctx, cam, spp=32, spp_offset=0)
+    hi, _, _ = _render(pt, gpu_ctx, cam, spp=32, spp_offset=32)
+    assert np.allclose((lo.astype(np.float64) + hi) / 2, full, rtol=3e-7, atol=1e-9)
+    assert not np.array_equal(lo, hi)
+
+
+def test_rgba8_plane_is_the_gamma_quantised_linear_plane(pt, gpu_ctx):     # world.rs:322-332
+    gpu_ctx.upload(pt.builtin_scene(1))
+    lin, rgba, _ = _render(pt, gpu_ctx, pt.camera_new(width=256, height=256), spp=16)
+    q = np.floor(np.clip(np.sqrt(lin.astype(np.float64)), 0, 1) * 255.0)
+    assert (np.abs(q - rgba[..., :3]) <= 1).all() and (q == rgba[..., :3]).mean() > 0.99
+    assert np.all(rgba[..., 3] == 255)
+
+
+def test_c4_ten_thousand_spheres_full_width_determinism(pt, gpu_ctx):
+    """The tiled-LDS path at the C4 scene size: deterministic and band-invariant (1024 wide, 64 rows, 8 spp)."""
+    gpu_ctx.upload(pt.builtin_scene(4, 10000))
+    cam = pt.camera_new(width=1024, height=64)
+    a, a8, sa = _render(pt, gpu_ctx, cam, spp=8)
+    b, b8, sb = _render(pt, gpu_ctx, cam, spp=8, max_paths_in_flight=3 * 1024 * 64, workgroups=100)
+    assert np.array_equal(a, b) and np.array_equal(a8, b8) and sa.vertices == sb.vertices
+    frame = np.zeros_like(a)
+    for g in range(4):
+        t, _, _ = _render(pt, gpu_ctx, cam, spp=8, band_rows=8, band_index=g, band_count=4)
+        frame[pt.tile_row_indices(64, 8, g, 4)] = t
+    assert np.array_equal(frame, a)
+
+
+def test_furnace_brdf_only_on_gpu(pt, gpu_ctx):
+    """Convex Lambertian sphere (albedo rho) in a uniform emitter Le: outgoing radiance = rho * Le."""
+    rho, le = 0.6, 2.0
+    gpu_ctx.upload(pt.make_objects([(0, [0, 0, -3, 1.0], 0, [rho] * 3), (0, [0, 0, 0, 40.0], 1, [le] * 3)]))
+    lin, _, _ = _render(pt, gpu_ctx, pt.camera_new(width=128, height=128, fov_degrees=10.0), spp=256, integrator=1)
+    assert lin.mean() == pytest.approx(rho * le, rel=2e-3)
+
+
+def test_mis_equals_brdf_only_without_roulette_on_gpu(pt, gpu_ctx):
+    gpu_ctx.upload(pt.builtin_scene(2))
+    cam = pt.camera_new(width=128, height=128)
+    mis, _, _ = _render(pt, gpu_ctx, cam, spp=256, min_depth=60000, max_depth=60001)
+    bo, _, st = _render(pt, gpu_ctx, cam, spp=1024, min_depth=60000, max_depth=60001, integrator=1)
+    assert mis.mean() == pytest.approx(bo.mean(), rel=5e-3)
+    assert st.max_depth_reached > 50                         # long paths drain through repeated bounce groups
+
+
+def test_edge_sizes(pt, orc, gpu_ctx):
+    """Smallest legal image, one sample, one-pixel-row tile, an empty tile, odd sizes."""
+    objs = pt.builtin_scene(1)
+    gpu_ctx.upload(objs)
+    for (w, h, spp) in [(2, 2, 1), (3, 5, 1), (65, 2, 3), (2, 67, 2)]:
+        cam = pt.camera_new(width=w, height=h)
+        prm = pt.default_params(spp=spp)
+        lin, rgba = gpu_ctx.render(cam, prm)
+        ref, ref8, _ = orc.render(cam, objs, prm, orc.F32, orc.ITERATIVE)
+        assert np.array_equal(lin.cpu().numpy(), ref.astype(np.float32)) and np.array_equal(rgba.cpu().numpy(), ref8)
+    cam = pt.camera_new(width=8, height=8)
+    lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=2, band_rows=64, band_index=1, band_count=2))
+    assert lin.shape[0] == 0 and gpu_ctx.stats().samples == 0
