@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the rendering hot path on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one complete render of the workload through the C ABI (pt_render_device):
+camera-ray generation, every bounce launch, film resolve, and for N > 1 the single
+RCCL gather of the framebuffer to rank 0.  Scene and camera are resident in HBM
+before the timed region; outputs stay in HBM (no PCIe in the timed region).
+
+Workload (BASELINE.json configs[1]): 10-sphere diffuse Cornell scene ("C2"),
+1024x1024, 64 spp, MIS integrator, reference path-depth policy.  N > 1 is WEAK scaling:
+the image stays 1024x1024 and the sample count grows to 64*N spp, rows are dealt to
+the ranks in interleaved bands, so every rank traces exactly the N = 1 number of
+samples (1024*1024*64) and the gathered frame is still 1024x1024.
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (k_bounce)
+with the ALGORITHMIC bytes of SURVEY 8(d): 252 B per path vertex + 64 B per camera
+sample, divided by the HIP-event time of the bounce launches measured in this run.
+`cpu_baseline` times the oracle (CPU restatement of the reference, f64 recursive,
+std::thread over pixels like rayon) on a bounded sample of the same workload; the
+Rust reference itself cannot be built here or on the GPU box (no cargo/rustc).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH = HEIGHT = 1024
+SPP = 64
+BYTES_PER_VERTEX = 252      # extend 32 + shade 144 + shadow/accumulate 68 + compaction 8
+BYTES_PER_SAMPLE = 64       # ray generation 52 + final radiance 12
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
+
+
+def cpu_baseline(pt, objs):
+    """Oracle (kind "port") on the host: C2 at the bench camera, a row subset spread over the image.
+    Threads = the box's CPU share for one GPU (16), never more than the affinity mask allows.  A short
+    probe sizes the sample so that the timed run is ~10 s of wall time (bounded)."""
+    from oracle import orc
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    cam = pt.camera_new(width=WIDTH, height=HEIGHT)
+
+    def run(spp, band_count):
+        prm = pt.default_params(spp=spp, band_rows=1, band_index=0, band_count=band_count)
+        t0 = time.perf_counter()
+        lin, _, _ = orc.render(cam, objs, prm, orc.F64, orc.RECURSIVE, threads=cores)
+        return lin.shape[0], time.perf_counter() - t0
+
+    rows, dt = run(1, 16)                                   # probe: 64 rows x 1 spp
+    rate = rows * WIDTH / dt                                # samples / s
+    band_count = 8                                          # timed: every 8th row (128 rows)
+    spp = int(min(SPP, max(1, round(10.0 * rate / (128 * WIDTH)))))
+    rows, dt = run(spp, band_count)
+    samples = rows * WIDTH * spp
+    return {
+        "value": round(samples / dt / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"C2 scene, {WIDTH}x{HEIGHT} camera, every {band_count}th row ({rows} rows), {spp} of {SPP} spp = "
+                  f"{samples} samples in {dt:.2f} s wall; oracle f64 recursive (reference-shaped: linear scan, "
+                  f"3 scans per vertex), {cores} threads over pixels ({avail} CPUs visible)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-paths", type=int, default=0, help="PtRenderParams.max_paths_in_flight (0 = default)")
+    ap.add_argument("--workgroups", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pathtrace_amd as pt
+    from pathtrace_amd.dist import default_band_rows, gather_tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    objs = pt.builtin_scene(2)
+    cam = pt.camera_new(width=WIDTH, height=HEIGHT)
+    spp = SPP * world
+    band_rows = default_band_rows(HEIGHT, world) if world > 1 else 0
+    prm = pt.default_params(spp=spp, band_rows=band_rows, band_index=rank, band_count=world, profile=1,
+                            max_paths_in_flight=args.max_paths, workgroups=args.workgroups)
+    ctx = pt.Context(local_rank)
+    ctx.upload(objs)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    rows = pt.tile_rows(HEIGHT, band_rows, rank, world)
+    lin = torch.empty((rows, WIDTH, 3), dtype=torch.float32, device=dev)
+    rgba = torch.empty((rows, WIDTH, 4), dtype=torch.uint8, device=dev)
+
+    acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0}
+
+    def step(record):
+        ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
+        ctx.sync()
+        frame = frame8 = None
+        if world > 1:
+            frame = gather_tiles(lin, HEIGHT, band_rows, rank, world)
+            frame8 = gather_tiles(rgba, HEIGHT, band_rows, rank, world)
+        if record:
+            st = ctx.stats()
+            acc["vertices"] += st.vertices
+            acc["samples"] += st.samples
+            acc["bounce_ms"] += st.bounce_kernel_ms
+            acc["launches"] += st.bounce_launches
+            acc["total_ms"] += st.total_ms
+        return frame, frame8
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame, frame8 = step(True)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([acc["vertices"], acc["samples"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        job_samples = float(tot[1].item())
+    else:
+        job_samples = float(acc["samples"])
+
+    if rank == 0:
+        if world > 1:
+            assert frame is not None and tuple(frame.shape) == (HEIGHT, WIDTH, 3) and torch.isfinite(frame).all()
+        else:
+            assert torch.isfinite(lin).all()
+        alg_bytes = BYTES_PER_VERTEX * acc["vertices"] + BYTES_PER_SAMPLE * acc["samples"]
+        achieved = alg_bytes / (acc["bounce_ms"] * 1e-3) / 1e9 if acc["bounce_ms"] > 0 else 0.0
+        out = {
+            "metric": "Msamples/sec (pixels x spp / s) at 1024^2/64spp",
+            "value": round(job_samples / elapsed / 1e6, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: 10-sphere diffuse Cornell scene, {WIDTH}x{HEIGHT}, {spp} spp "
+                            f"({SPP} spp per GPU), MIS, min_depth 4 / max_depth 50",
+                "samples_per_step": int(job_samples / args.steps),
+                "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
+                "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "
+                                                          "one RCCL gather of the f32 + RGBA8 frame to rank 0",
+            },
+            "roofline": {
+                "kernel": "k_bounce (all bounce launches of rank 0)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["launches"], 1)),
+                "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 4),
+                "launches": acc["launches"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pt, objs)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
