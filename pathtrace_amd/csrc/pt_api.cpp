@@ -65,7 +65,7 @@ struct PtContext {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // scene
-    DevBuf<float4> scan, shape, mat;
+    DevBuf<float4> scan, shape, mat, blob;
     DevBuf<ptk::Run> runs;
     DevBuf<uint32_t> lights;
     ptk::SceneView view{};
@@ -75,11 +75,9 @@ struct PtContext {
     DevBuf<float4> lsamp;
     DevBuf<uint32_t> counters, seg_count;
     DevBuf<unsigned long long> dstats;
-    DevBuf<uint32_t> rows;
     DevBuf<double> film;
     uint32_t* h_counters = nullptr;   // pinned
     unsigned long long* h_dstats = nullptr;
-    std::vector<uint32_t> rows_host;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     PtStats stats{};
@@ -166,9 +164,9 @@ int pt_context_destroy(PtContext* c) {
     if (!c) return PT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->scan.release(); c->shape.release(); c->mat.release(); c->runs.release(); c->lights.release();
+    c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     for (auto& b : c->queue) b.release();
-    c->lsamp.release(); c->counters.release(); c->seg_count.release(); c->dstats.release(); c->rows.release(); c->film.release();
+    c->lsamp.release(); c->counters.release(); c->seg_count.release(); c->dstats.release(); c->film.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_dstats) (void)hipHostFree(c->h_dstats);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -250,6 +248,24 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     if (!lights.empty()) HIP_TRY(hipMemcpy(c->lights.p, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->view.scan = c->scan.p; c->view.shape = c->shape.p; c->view.mat = c->mat.p;
     c->view.runs = c->runs.p; c->view.lights = c->lights.p;
+    c->view.blob = nullptr; c->view.blob_f4 = 0;
+    if (n <= ptk::kSmallObjs) {
+        // LDS image of a small scene: [scan | shape 3n | mat 2n | runs | lights (padded to 16 B)]
+        std::vector<float4> blob(scan.begin(), scan.end());
+        blob.insert(blob.end(), shape.begin(), shape.begin() + 3 * (size_t)n);
+        blob.insert(blob.end(), mat.begin(), mat.begin() + 2 * (size_t)n);
+        static_assert(sizeof(ptk::Run) == sizeof(float4), "Run must be one float4");
+        for (const ptk::Run& r : runs) { float4 f; std::memcpy(&f, &r, sizeof f); blob.push_back(f); }
+        for (size_t i = 0; i < lights.size(); i += 4) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (size_t k = 0; k < 4 && i + k < lights.size(); ++k) w[k] = lights[i + k];
+            float4 f; std::memcpy(&f, w, sizeof f); blob.push_back(f);
+        }
+        if ((rc = c->blob.ensure(blob.size() + 1))) return rc;
+        if (!blob.empty()) HIP_TRY(hipMemcpy(c->blob.p, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
+        c->view.blob = c->blob.p;
+        c->view.blob_f4 = (uint32_t)blob.size();
+    }
     c->view.scan_f4 = (uint32_t)scan.size();
     c->view.n_runs = (uint32_t)runs.size(); c->view.n_objs = n; c->view.n_lights = (uint32_t)lights.size();
     c->has_scene = true;
@@ -273,6 +289,8 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     std::memset(&c->stats, 0, sizeof c->stats);
     if (np64 == 0) return PT_OK;   // empty tile: nothing to render
     if (!d_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_device: d_linear_rgb is null");
+    if (cam->width > 65535u || rows.size() > 65535u)   // (tile row, x) share one word of the path state
+        return fail(PT_ERR_UNSUPPORTED, "tile %ux%zu: width and tile rows must be < 65536", cam->width, rows.size());
     uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : kDefaultMaxPaths;
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)
@@ -303,13 +321,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     if ((rc = c->counters.ensure(n_counter))) return rc;
     if ((rc = c->seg_count.ensure(nw))) return rc;
     if ((rc = c->dstats.ensure(8))) return rc;
-    if ((rc = c->rows.ensure(rows.size()))) return rc;
     if (n_batches > 1 && (rc = c->film.ensure((size_t)np * 3))) return rc;
-    if (rows != c->rows_host) {
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(c->rows.p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->rows_host = rows;
-    }
 
     ptk::BounceArgs a{};
     for (int k = 0; k < 4; ++k) a.q.q[k] = c->queue[k].p;
@@ -318,7 +330,13 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     a.lsamp = c->lsamp.p;
     a.counters = c->counters.p;
     a.stats = c->dstats.p;
-    a.rows = c->rows.p;
+    {   // tile row -> image row without a table (ptk::TileMap)
+        const uint32_t br = prm->band_rows ? prm->band_rows : cam->height;
+        a.tile.band_rows = br;
+        a.tile.band_magic = br > 1 ? (uint32_t)(((1ull << 32) + br - 1) / br) : 0u;
+        a.tile.band_stride = br * band_count;
+        a.tile.band_first = prm->band_index * br;
+    }
     a.sc = c->view;
     for (int k = 0; k < 3; ++k) {
         a.cam.origin[k] = (float)cam->origin[k]; a.cam.lower_left[k] = (float)cam->lower_left[k];

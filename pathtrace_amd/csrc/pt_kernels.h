@@ -22,6 +22,10 @@ struct SceneView {
     const float4* mat;       // 2 float4 per object
     const Run* runs;
     const uint32_t* lights;  // object indices of the emitters (world.rs:214-225)
+    // scenes of <= kSmallObjs objects: the five arrays above packed back to back
+    // [scan | shape | mat | runs | lights], copied whole into LDS by every workgroup
+    const float4* blob;
+    uint32_t blob_f4;        // float4 count of `blob` (0 for larger scenes)
     uint32_t scan_f4;        // float4 count of `scan`
     uint32_t n_runs, n_objs, n_lights;
 };
@@ -33,21 +37,30 @@ struct CameraF {             // Camera's cached fields in f32 (camera.rs:36-38)
 
 // Path-state queue: 4 float4 planes, index = queue slot (coalesced 16 B/lane).
 //   q0 = (o.x, o.y, o.z, d.x)  q1 = (d.y, d.z, beta.x, beta.y)
-//   q2 = (beta.z, L.x, L.y, L.z)  q3 = (pdf_prev, eta_in, bits(pid), bits(s_local<<16 | depth))
+//   q2 = (beta.z, L.x, L.y, L.z)
+//   q3 = (pdf_prev, eta_in, bits(tile_row<<16 | x), bits(s_local<<16 | depth))
+// so width, tile rows and samples per batch are each < 65536.
 struct Queue {
     float4* q[4];
 };
 
 constexpr uint32_t kCounterShards = 16;
 
+// Row-band tile (include/pathtrace_amd.h): tile row yl -> image row
+//   y = (yl / band_rows) * band_stride + band_first + yl % band_rows
+// with yl / band_rows = umulhi(yl, band_magic) (exact for yl, band_rows < 65536).
+struct TileMap {
+    uint32_t band_rows, band_magic, band_stride, band_first;
+};
+
 struct BounceArgs {
     Queue q;                  // compacted in place, one private segment per wave
     uint32_t* seg_count;      // [wave] queued paths of the wave's segment (in: this bounce, out: next)
     uint32_t seg_cap;         // slots per segment (multiple of 64)
-    float4* lsamp;            // per-path final radiance, index = pid
+    float4* lsamp;            // per-path final radiance, index = s_local*np + tile_row*width + x
     uint32_t* counters;       // counters[b*kCounterShards + s]: sharded total of paths entering bounce b
     unsigned long long* stats;  // [0] shadow rays
-    const uint32_t* rows;     // tile-local row -> image row
+    TileMap tile;
     SceneView sc;
     CameraF cam;
     uint32_t bounce;          // b
@@ -60,8 +73,11 @@ struct BounceArgs {
 };
 
 constexpr uint32_t kBlock = 256;
-constexpr uint32_t kSmallSceneF4 = 1024;   // scenes whose scan array is <= 16 KiB stay whole in LDS
-constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tiles otherwise (divisible by 3: whole triangles)
+// Scenes of at most kSmallObjs objects stay whole in LDS (scan + shape + material + run
+// records: at most 9 float4 per object = 18 KiB); larger scenes stream their scan array
+// through one LDS tile and gather shape/material records from global memory.
+constexpr uint32_t kSmallObjs = 128;
+constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tile (divisible by 3: whole triangles)
 
 // grid = number of 256-thread workgroups; it fixes the number of queue segments
 // (4 per workgroup) and must not change between the bounces of one batch

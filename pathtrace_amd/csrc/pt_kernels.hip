@@ -66,7 +66,16 @@ PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& c
 PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float a,
                      float inv_a, float t_min, float& closest, int& id) {
     if (tag == SHAPE_SPHERE) {
-        for (uint32_t i = 0; i < n; ++i) sphere_test(p[i], o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
+        // four LDS reads in flight per wait instead of one
+        uint32_t i = 0;
+        for (; i + 4u <= n; i += 4u) {
+            float4 s0 = p[i], s1 = p[i + 1], s2 = p[i + 2], s3 = p[i + 3];
+            sphere_test(s0, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
+            sphere_test(s1, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 1);
+            sphere_test(s2, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 2);
+            sphere_test(s3, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 3);
+        }
+        for (; i < n; ++i) sphere_test(p[i], o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
     } else {
         for (uint32_t i = 0; i < n; ++i) {
             float4 a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
@@ -76,13 +85,44 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
     }
 }
 
+// Where the kernel finds the scene.  SMALL: everything is in LDS (the blob of
+// SceneView, copied once per workgroup).  Otherwise the scan array streams through
+// the LDS tile and the per-object records are gathered from global memory.
+struct SceneRef {
+    const float4* scan;     // SMALL: LDS scan array; else: the LDS tile buffer
+    const float4* shape;
+    const float4* mat;
+    const Run* runs;
+    const uint32_t* lights;
+    const float4* scan_global;
+    uint32_t n_runs, n_lights;
+};
+template <bool SMALL>
+PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
+    SceneRef r;
+    r.n_runs = sc.n_runs; r.n_lights = sc.n_lights;
+    r.scan_global = sc.scan;
+    if (SMALL) {
+        for (uint32_t k = threadIdx.x; k < sc.blob_f4; k += kBlock) lds[k] = sc.blob[k];
+        __syncthreads();
+        r.scan = lds;
+        r.shape = lds + sc.scan_f4;
+        r.mat = lds + sc.scan_f4 + 3u * sc.n_objs;
+        r.runs = reinterpret_cast<const Run*>(lds + sc.scan_f4 + 5u * sc.n_objs);
+        r.lights = reinterpret_cast<const uint32_t*>(lds + sc.scan_f4 + 5u * sc.n_objs + sc.n_runs);
+    } else {
+        r.scan = lds;
+        r.shape = sc.shape; r.mat = sc.mat; r.runs = sc.runs; r.lights = sc.lights;
+    }
+    return r;
+}
+
 // World::hit_scene (world.rs:270-290): linear scan in object order with a
 // shrinking t_max.  SMALL: the whole scan array already sits in LDS.  Otherwise
 // every run is streamed through one LDS tile; the loop is block-uniform (all
 // threads of the workgroup call this together, active or not).
 template <bool SMALL>
-PT_DEV void scan_closest(const SceneView& sc, float4* lds, f3 o, f3 d, float t_min, float t_max, int& id_out,
-                         float& t_out) {
+PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
     float a = dot(d, d);
     float inv_a = 1.0f / a;
     float closest = t_max;
@@ -91,21 +131,28 @@ PT_DEV void scan_closest(const SceneView& sc, float4* lds, f3 o, f3 d, float t_m
         Run run = sc.runs[r];
         const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
         if (SMALL) {
-            scan_run(lds + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
+            scan_run(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
         } else {
+            float4* tile = const_cast<float4*>(sc.scan);
             const uint32_t tile_prims = kTileF4 / per;
             for (uint32_t p0 = 0; p0 < run.count; p0 += tile_prims) {
                 uint32_t np = run.count - p0 < tile_prims ? run.count - p0 : tile_prims;
                 __syncthreads();
-                const float4* src = sc.scan + run.off4 + p0 * per;
-                for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) lds[k] = src[k];
+                const float4* src = sc.scan_global + run.off4 + p0 * per;
+                for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) tile[k] = src[k];
                 __syncthreads();
-                scan_run(lds, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
+                scan_run(tile, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
             }
         }
     }
     id_out = id;
     t_out = closest;
+}
+
+// tile row -> image row (TileMap)
+PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
+    uint32_t q = t.band_rows == 1u ? yl : __umulhi(yl, t.band_magic);
+    return q * t.band_stride + t.band_first + (yl - q * t.band_rows);
 }
 
 // ------------------------------------------------------------------ bounce kernel
@@ -120,14 +167,17 @@ PT_DEV void scan_closest(const SceneView& sc, float4* lds, f3 o, f3 d, float t_m
 // measured 59 ms of a 60 ms render at 1024^2 x 64 spp.)
 // Bounce 0 deals 64-path chunks round-robin to the waves (chunk k -> wave k % nw)
 // so that every segment samples the whole image and segments decay alike.
+//
+// Memory pipeline of one iteration: the NEXT chunk's state is requested at the top
+// (4 x 16 B per lane in flight during the whole vertex computation) and consumed
+// just BEFORE this iteration's stores, so the only vector-memory wait of the loop
+// sits behind ~5000 cycles of work and never behind a store.  With a SMALL scene
+// nothing else in the loop touches global memory.
 template <bool FIRST, bool SMALL, bool MIS>
 __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
-    if (SMALL) {
-        for (uint32_t k = threadIdx.x; k < a.sc.scan_f4; k += kBlock) lds[k] = a.sc.scan[k];
-        __syncthreads();
-    }
+    const SceneRef sc = stage_scene<SMALL>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (kBlock / 64);
@@ -144,40 +194,50 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
         n_iter = m;
     }
     const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+    const uint32_t W = a.cam.width;
     uint32_t out_n = 0;          // wave-uniform: survivors written so far
     uint32_t wave_shadow = 0;
 
+    // state of the next chunk, in flight
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
+    if (!FIRST && lane < n_in) {
+        const uint32_t s0 = seg_base + lane;
+        n0 = a.q.q[0][s0]; n1 = a.q.q[1][s0]; n2 = a.q.q[2][s0]; n3 = a.q.q[3][s0];
+    }
+
     for (uint32_t it = 0; it < n_iter; ++it) {
-        const uint32_t slot = seg_base + it * 64u + lane;
         bool active;
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f), beta = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
         float pdf_prev = 0.0f, eta_in = 1.0f;
-        uint32_t pid = 0, s_local = 0, depth = 0, px = 0, py = 0;
+        uint32_t s_local = 0, depth = 0, px = 0, yl = 0, py = 0;
 
         if (FIRST) {
             const uint32_t chunk = it * nw + wave;
-            pid = chunk * 64u + lane;
+            const uint32_t pid = chunk * 64u + lane;
             active = chunk < n_chunks && pid < a.n_first;
-            if (active) s_local = pid / a.np;
+            if (active) {
+                s_local = pid / a.np;
+                const uint32_t pix = pid - s_local * a.np;
+                yl = pix / W;
+                px = pix - yl * W;
+            }
         } else {
             active = it * 64u + lane < n_in;
-            if (active) {
-                float4 q0 = a.q.q[0][slot], q1 = a.q.q[1][slot], q2 = a.q.q[2][slot], q3 = a.q.q[3][slot];
-                o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y);
-                beta = mk(q1.z, q1.w, q2.x); L = mk(q2.y, q2.z, q2.w);
-                pdf_prev = q3.x; eta_in = q3.y;
-                pid = __float_as_uint(q3.z);
-                uint32_t sd = __float_as_uint(q3.w);
-                s_local = sd >> 16; depth = sd & 0xFFFFu;
+            o = mk(n0.x, n0.y, n0.z); d = mk(n0.w, n1.x, n1.y);
+            beta = mk(n1.z, n1.w, n2.x); L = mk(n2.y, n2.z, n2.w);
+            pdf_prev = n3.x; eta_in = n3.y;
+            const uint32_t xy = __float_as_uint(n3.z), sd = __float_as_uint(n3.w);
+            yl = xy >> 16; px = xy & 0xFFFFu;
+            s_local = sd >> 16; depth = sd & 0xFFFFu;
+            if (!active) { o = mk(0.f, 0.f, 0.f); d = o; }
+            // request the next chunk now; it is consumed just before this iteration's stores
+            const uint32_t nxt = (it + 1u) * 64u + lane;
+            if (nxt < n_in) {
+                const uint32_t s1 = seg_base + nxt;
+                n0 = a.q.q[0][s1]; n1 = a.q.q[1][s1]; n2 = a.q.q[2][s1]; n3 = a.q.q[3][s1];
             }
         }
-        if (active) {
-            // pixel of the path: key of its RNG stream = (x, y), main.rs:51
-            uint32_t pix = pid - s_local * a.np;
-            uint32_t yl = pix / a.cam.width;
-            px = pix - yl * a.cam.width;
-            py = a.rows[yl];
-        }
+        py = image_row(a.tile, yl);                  // key of the path's RNG stream = (x, y), main.rs:51
         const uint32_t sample = a.s_base + s_local;
 
         if (FIRST && active) {
@@ -195,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
-        scan_closest<SMALL>(a.sc, lds, o, d, a.t_min, kInf, id, t);
+        scan_closest<SMALL>(sc, o, d, a.t_min, kInf, id, t);
         bool alive = active && id >= 0;
 
         Hit hit;
@@ -204,8 +264,8 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
         m.tag = MAT_LAMBERT; m.shape_tag = 0; m.emits = 0; m.color = mk(0.f, 0.f, 0.f);
         m.roughness = 0.f; m.metallic = 0.f; m.ior = 1.f; m.on_a = 1.f; m.on_b = 0.f;
         if (alive) {
-            m = load_mat(a.sc.mat, id);
-            hit = finish_hit(a.sc.shape, id, m.shape_tag, o, d, t);
+            m = load_mat(sc.mat, id);
+            hit = finish_hit(sc.shape, id, m.shape_tag, o, d, t);
             if (m.emits) {
                 if (!MIS || depth == 0u) {
                     L = L + beta * m.color;                                       // rendering.rs:44-45 / :225-227
@@ -213,7 +273,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
                     // emitter reached by a BSDF-sampled ray: MIS weight against the light
                     // pdf seen from the previous vertex = this ray's origin (rendering.rs:107-121)
                     f3 sp; float pdf_shape;
-                    shape_sample(a.sc.shape, id, m.shape_tag, o, true, hit.point, 0.f, 0.f, sp, pdf_shape);
+                    shape_sample(sc.shape, id, m.shape_tag, o, true, hit.point, 0.f, 0.f, sp, pdf_shape);
                     float w_bsdf = pdf_prev / (pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
                     L = L + beta * m.color * w_bsdf;
                 }
@@ -225,17 +285,17 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
         bool need_shadow = false;
         f3 light_dir = mk(0.f, 0.f, 0.f), ls_emission = mk(0.f, 0.f, 0.f);
         float distance = 0.0f, ls_pdf = 1.0f;
-        if (MIS && alive && a.sc.n_lights > 0u) {
+        if (MIS && alive && sc.n_lights > 0u) {
             uint32_t dl[4];
             philox4x32_10(sample, depth, BLK_LIGHT, 0u, px, py, dl);
-            uint32_t li = __umulhi(dl[0], a.sc.n_lights);                         // random_range(0..n), world.rs:255
-            int lobj = (int)a.sc.lights[li];
-            Mat lm = load_mat(a.sc.mat, lobj);
+            uint32_t li = __umulhi(dl[0], sc.n_lights);                           // random_range(0..n), world.rs:255
+            int lobj = (int)sc.lights[li];
+            Mat lm = load_mat(sc.mat, lobj);
             f3 lp; float pdf_shape;
-            shape_sample(a.sc.shape, lobj, lm.shape_tag, hit.point, false, hit.point, u01(dl[1]), u01(dl[2]), lp,
+            shape_sample(sc.shape, lobj, lm.shape_tag, hit.point, false, hit.point, u01(dl[1]), u01(dl[2]), lp,
                          pdf_shape);
             ls_emission = lm.color;                                               // world.rs:259
-            ls_pdf = pdf_shape / (float)a.sc.n_lights;                            // world.rs:260
+            ls_pdf = pdf_shape / (float)sc.n_lights;                              // world.rs:260
             f3 to_light = lp - hit.point;                                         // rendering.rs:58-60
             distance = length(to_light);
             light_dir = normalize(to_light);
@@ -250,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
                 f3 sdir = need_shadow ? normalize(light_dir) : mk(0.f, 0.f, 0.f);   // Ray::new normalises again
                 f3 sorg = need_shadow ? hit.point : mk(0.f, 0.f, 0.f);
                 int sid; float st;
-                scan_closest<SMALL>(a.sc, lds, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
+                scan_closest<SMALL>(sc, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
                 visible = need_shadow && sid < 0;
                 wave_shadow += (uint32_t)__popcll(__ballot(need_shadow));
             }
@@ -278,7 +338,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
                 alive = false;
             } else {
                 L = L + beta * direct;
-                beta = next_tp / rr;                                              // :129
+                beta = rr == 1.0f ? next_tp : next_tp / rr;                       // :129 (x * (1/1) == x exactly)
                 if (is_zero(beta) || depth >= 65534u) {                           // Q7: nothing downstream contributes
                     alive = false;
                 } else {
@@ -291,15 +351,24 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
             }
         }
 
+        // ---- the next chunk must have landed before anything is stored (in-place queue)
+        if (!FIRST) {
+            asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z),
+                         "+v"(n1.w));
+            asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z),
+                         "+v"(n3.w));
+        }
+
         // ---- retire, or compact in place into the wave's own segment
-        if (active && !alive) a.lsamp[pid] = make_float4(L.x, L.y, L.z, 0.0f);
+        if (active && !alive) a.lsamp[s_local * a.np + yl * W + px] = make_float4(L.x, L.y, L.z, 0.0f);
         const unsigned long long mask = __ballot(alive);
         if (alive) {
             const uint32_t j = seg_base + out_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             a.q.q[0][j] = make_float4(o.x, o.y, o.z, d.x);
             a.q.q[1][j] = make_float4(d.y, d.z, beta.x, beta.y);
             a.q.q[2][j] = make_float4(beta.z, L.x, L.y, L.z);
-            a.q.q[3][j] = make_float4(pdf_prev, eta_in, __uint_as_float(pid), __uint_as_float((s_local << 16) | depth));
+            a.q.q[3][j] = make_float4(pdf_prev, eta_in, __uint_as_float((yl << 16) | px),
+                                      __uint_as_float((s_local << 16) | depth));
         }
         out_n += (uint32_t)__popcll(mask);
     }
@@ -311,15 +380,20 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
     }
 }
 
+static size_t scene_lds_bytes(const SceneView& sc) {
+    const bool small = sc.n_objs <= kSmallObjs;
+    return (small ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
+}
+
 template <bool FIRST, bool SMALL, bool MIS>
 static void launch_bounce_t(const BounceArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
     hipLaunchKernelGGL((k_bounce<FIRST, SMALL, MIS>), dim3(grid), dim3(kBlock), lds_bytes, st, a);
 }
 
 void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st) {
-    const bool small = a.sc.scan_f4 <= kSmallSceneF4;
+    const bool small = a.sc.n_objs <= kSmallObjs;
     const bool mis = a.integrator == 0;
-    const size_t lds = (small ? (a.sc.scan_f4 ? a.sc.scan_f4 : 1u) : kTileF4) * sizeof(float4);
+    const size_t lds = scene_lds_bytes(a.sc);
 #define PT_CASE(F, S, M) \
     if (first == F && small == S && mis == M) { launch_bounce_t<F, S, M>(a, grid, lds, st); return; }
     PT_CASE(true, true, true) PT_CASE(true, true, false) PT_CASE(true, false, true) PT_CASE(true, false, false)
@@ -363,13 +437,10 @@ void launch_resolve(const ResolveArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ debug: hit_scene on arbitrary rays
 template <bool SMALL>
-__global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView sc, const float* __restrict__ rays6, uint32_t n,
+__global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float* __restrict__ rays6, uint32_t n,
                                                       float t_min, float t_max, int32_t* out_id, float* out_t) {
     extern __shared__ float4 lds[];
-    if (SMALL) {
-        for (uint32_t k = threadIdx.x; k < sc.scan_f4; k += kBlock) lds[k] = sc.scan[k];
-        __syncthreads();
-    }
+    const SceneRef sc = stage_scene<SMALL>(scv, lds);
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < n;
@@ -379,22 +450,22 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView sc, const float*
             d = normalize(mk(rays6[6 * (size_t)i + 3], rays6[6 * (size_t)i + 4], rays6[6 * (size_t)i + 5]));
         }
         int id; float t;
-        scan_closest<SMALL>(sc, lds, o, d, t_min, t_max, id, t);
+        scan_closest<SMALL>(sc, o, d, t_min, t_max, id, t);
         if (active) { out_id[i] = id; out_t[i] = id >= 0 ? t : 0.0f; }
     }
 }
 void launch_debug_hit(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max, int32_t* out_id,
                       float* out_t, hipStream_t st) {
-    const bool small = sc.scan_f4 <= kSmallSceneF4;
+    const bool small = sc.n_objs <= kSmallObjs;
     uint32_t grid = (n + kBlock - 1) / kBlock;
     if (grid > 2048u) grid = 2048u;
     if (grid == 0u) grid = 1u;
     if (small)
-        hipLaunchKernelGGL(k_debug_hit<true>, dim3(grid), dim3(kBlock), (sc.scan_f4 ? sc.scan_f4 : 1u) * sizeof(float4),
-                           st, sc, rays6, n, t_min, t_max, out_id, out_t);
+        hipLaunchKernelGGL(k_debug_hit<true>, dim3(grid), dim3(kBlock), scene_lds_bytes(sc), st, sc, rays6, n, t_min,
+                           t_max, out_id, out_t);
     else
-        hipLaunchKernelGGL(k_debug_hit<false>, dim3(grid), dim3(kBlock), kTileF4 * sizeof(float4), st, sc, rays6, n,
-                           t_min, t_max, out_id, out_t);
+        hipLaunchKernelGGL(k_debug_hit<false>, dim3(grid), dim3(kBlock), scene_lds_bytes(sc), st, sc, rays6, n, t_min,
+                           t_max, out_id, out_t);
 }
 
 }  // namespace ptk
