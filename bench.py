@@ -60,8 +60,12 @@ def cpu_baseline(pt, objs):
 
     rows, dt = run(1, 16)                                   # probe: 64 rows x 1 spp
     rate = rows * WIDTH / dt                                # samples / s
-    band_count = 8                                          # timed: every 8th row (128 rows)
-    spp = int(min(SPP, max(1, round(10.0 * rate / (128 * WIDTH)))))
+    # timed run: full 64 spp on every band_count-th row, band_count chosen for ~10 s of wall time
+    band_count = 16
+    for bc in (8, 4, 2, 1):
+        if (HEIGHT // bc) * WIDTH * SPP / rate <= 12.0:
+            band_count = bc
+    spp = SPP if (HEIGHT // band_count) * WIDTH * SPP / rate <= 30.0 else int(max(1, 30.0 * rate / (64 * WIDTH)))
     rows, dt = run(spp, band_count)
     samples = rows * WIDTH * spp
     return {

@@ -162,6 +162,11 @@ int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* 
 int pt_sync(PtContext* ctx);
 int pt_get_stats(PtContext* ctx, PtStats* out);
 
+/* Same render with HOST output buffers (blocking): device staging is owned by the
+ * context, results are copied back over PCIe.  out_rgba8 may be NULL.          */
+int pt_render_host(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
+                   float* out_linear_rgb, uint8_t* out_rgba8);
+
 /* One-shot convenience with HOST buffers: create context on device 0 (cached),
  * upload, render, copy back.  = everything src/main.rs:43-60 does.            */
 int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n_objs,

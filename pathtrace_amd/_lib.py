@@ -82,6 +82,7 @@ SYMBOLS = {
     "pt_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_sync": (C.c_int, [C.c_void_p]),
     "pt_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
+    "pt_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double,
                                      _P(C.c_int32), _P(C.c_float)]),
@@ -96,6 +97,13 @@ def lib():
     """Load libpathtrace_amd.so (built by `__graft_entry__.build()` / csrc/Makefile)."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64.so with the same SONAME as /opt/rocm's.  A process must
+        # run ONE HIP runtime: load torch's first so that this library binds to it too (device
+        # pointers and streams are exchanged with torch).  Without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP library first "

@@ -76,6 +76,8 @@ struct PtContext {
     DevBuf<uint32_t> counters, seg_count;
     DevBuf<unsigned long long> dstats;
     DevBuf<double> film;
+    DevBuf<float> host_lin;       // device staging of pt_render_host
+    DevBuf<uint8_t> host_rgba;
     uint32_t* h_counters = nullptr;   // pinned
     unsigned long long* h_dstats = nullptr;
     std::vector<hipEvent_t> ev_pool;
@@ -166,7 +168,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipStreamSynchronize(c->stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     for (auto& b : c->queue) b.release();
-    c->lsamp.release(); c->counters.release(); c->seg_count.release(); c->dstats.release(); c->film.release();
+    c->lsamp.release(); c->counters.release(); c->seg_count.release(); c->dstats.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_dstats) (void)hipHostFree(c->h_dstats);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -468,6 +470,23 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
     return PT_OK;
 }
 
+int pt_render_host(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* out_linear, uint8_t* out_rgba) {
+    if (!c || !cam || !prm || !out_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_host: null argument");
+    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
+    const size_t np = (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
+    if (np == 0) return pt_render_device(c, cam, prm, nullptr, nullptr);   // validates, renders nothing
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->host_lin.ensure(np * 3))) return rc;
+    if (out_rgba && (rc = c->host_rgba.ensure(np * 4))) return rc;
+    rc = pt_render_device(c, cam, prm, c->host_lin.p, out_rgba ? c->host_rgba.p : nullptr);
+    if (!rc) rc = pt_sync(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out_linear, c->host_lin.p, np * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, c->host_rgba.p, np * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRenderParams* prm, float* out_linear,
               uint8_t* out_rgba) {
     if (!cam || !prm || !out_linear) return fail(PT_ERR_INVALID_ARG, "pt_render: null argument");
@@ -477,21 +496,7 @@ int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRen
     int rc;
     if (!ctx && (rc = pt_context_create(0, &ctx))) return rc;
     if ((rc = pt_scene_upload(ctx, objs, n))) return rc;
-    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
-    const size_t np = (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
-    if (np == 0) return PT_OK;
-    float* d_lin = nullptr; uint8_t* d_rgba = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_lin, np * 3 * sizeof(float)));
-    if (out_rgba) HIP_TRY(hipMalloc((void**)&d_rgba, np * 4));
-    rc = pt_render_device(ctx, cam, prm, d_lin, d_rgba);
-    if (!rc) rc = pt_sync(ctx);
-    if (!rc) {
-        HIP_TRY(hipMemcpy(out_linear, d_lin, np * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, d_rgba, np * 4, hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_lin);
-    if (d_rgba) (void)hipFree(d_rgba);
-    return rc;
+    return pt_render_host(ctx, cam, prm, out_linear, out_rgba);
 }
 
 }  // extern "C"
