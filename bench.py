@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0, help="PtRenderParams.max_paths_in_flight (0 = default)")
     ap.add_argument("--workgroups", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
+                         "goes through host memory); the driver's runs use nccl (RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +104,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     objs = pt.builtin_scene(2)
     cam = pt.camera_new(width=WIDTH, height=HEIGHT)
@@ -113,7 +121,7 @@ def main():
     band_rows = default_band_rows(HEIGHT, world) if world > 1 else 0
     prm = pt.default_params(spp=spp, band_rows=band_rows, band_index=rank, band_count=world, profile=1,
                             max_paths_in_flight=args.max_paths, workgroups=args.workgroups)
-    ctx = pt.Context(local_rank)
+    ctx = pt.Context(dev_index)
     ctx.upload(objs)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     rows = pt.tile_rows(HEIGHT, band_rows, rank, world)
@@ -127,8 +135,8 @@ def main():
         ctx.sync()
         frame = frame8 = None
         if world > 1:
-            frame = gather_tiles(lin, HEIGHT, band_rows, rank, world)
-            frame8 = gather_tiles(rgba, HEIGHT, band_rows, rank, world)
+            frame = gather_tiles(lin.to(comm_dev), HEIGHT, band_rows, rank, world)
+            frame8 = gather_tiles(rgba.to(comm_dev), HEIGHT, band_rows, rank, world)
         if record:
             st = ctx.stats()
             acc["vertices"] += st.vertices
@@ -153,10 +161,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([acc["vertices"], acc["samples"]], dtype=torch.float64, device=dev)
+        tot = torch.tensor([acc["vertices"], acc["samples"]], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_samples = float(tot[1].item())
     else:
@@ -188,7 +196,7 @@ def main():
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
                 "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "
-                                                          "one RCCL gather of the f32 + RGBA8 frame to rank 0",
+                                                          f"one {args.backend} gather of the f32 + RGBA8 frame to rank 0",
             },
             "roofline": {
                 "kernel": "k_bounce (all bounce launches of rank 0)",
