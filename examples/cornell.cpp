@@ -2,7 +2,7 @@
 // build World::new(), render every pixel, export luminance.csv, and write a PPM of
 // World.data instead of blitting it to a winit/pixels surface (out of scope).
 //
-//   ./cornell [width height spp [out_prefix]]        defaults: 400 400 64 cornell
+//   ./cornell [width height spp [out_prefix [exact_math]]]        defaults: 400 400 64 cornell 0
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
     const uint32_t h = argc > 2 ? (uint32_t)std::atoi(argv[2]) : HEIGHT;
     const uint32_t spp = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 64;
     const std::string prefix = argc > 4 ? argv[4] : "cornell";
+    const uint32_t exact_math = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 0;
     try {
         // World::new() fixes 400x400; other sizes re-author the same scene with the same camera model
         World world = World::new_();
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
             }
         }
         world.params().spp = spp;
+        world.params().exact_math = exact_math;
         const auto t0 = std::chrono::steady_clock::now();
         world.render();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -136,6 +136,9 @@ template <> struct Ar<float> {
 };
 
 template <class R> constexpr R kPi() { return (R)3.14159265358979323846; }
+// f32 mode evaluates x / pi as x * (1/pi) with this constant
+constexpr float kInvPiF = 0.31830988618379067154f;
+template <class R> inline R div_pi(R x) { return Ar<R>::kFloat ? (R)((float)x * kInvPiF) : x / kPi<R>(); }
 template <class R> constexpr R kInf() { return std::numeric_limits<R>::infinity(); }
 
 // ------------------------------------------------------------------ Vector3 (math.rs:3-244)
@@ -203,6 +206,12 @@ template <class R> struct Ray {
     R eta_ratio;
     Ray() : eta_ratio(1) {}
     Ray(const V3<R>& o, const V3<R>& d) : origin(o), direction(d.normalize()), eta_ratio(1) {}   // camera.rs:10-16
+    // f32 mode: a direction that is already normalised is not normalised a second time (the reference's
+    // Ray::new does, changing the last bit at most); f64 keeps the reference's double normalisation.
+    static Ray from_unit(const V3<R>& o, const V3<R>& d) {
+        if (!Ar<R>::kFloat) return Ray(o, d);
+        Ray r; r.origin = o; r.direction = d; r.eta_ratio = 1; return r;
+    }
     V3<R> at(R t) const {                                                                         // camera.rs:18-20
         if (Ar<R>::kFloat) return madd(direction, t, origin);
         return origin + direction * t;
@@ -660,8 +669,8 @@ inline void oren_nayar_eval(const Obj<R>& m, const Ray<R>& ray, const V3<R>& o, 
     if (ci > co) { tan_beta = ci > R(1e-6) ? si / ci : R(0); sin_alpha = so; }
     else { tan_beta = co > R(1e-6) ? so / co : R(0); sin_alpha = si; }
     R term = m.on_a + m.on_b * cos_phi * sin_alpha * tan_beta;
-    f = m.color * (term / kPi<R>());
-    pdf = std::fmax(o.dot(n), R(0)) / kPi<R>();
+    f = m.color * div_pi<R>(term);
+    pdf = div_pi<R>(std::fmax(o.dot(n), R(0)));
 }
 
 // Object::bsdf_pdf (object.rs:35-43) -> Material::bsdf_pdf
@@ -669,8 +678,8 @@ template <class R>
 inline void bsdf_pdf(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& o, const V3<R>& n, V3<R>& f, R& pdf) {
     switch (ob.mat_tag) {
         case PT_MAT_LAMBERT:                                  // material.rs:86-91, 78-82
-            f = ob.color / kPi<R>();
-            pdf = std::fmax(o.dot(n), R(0)) / kPi<R>();
+            f = Ar<R>::kFloat ? ob.color * (R)kInvPiF : ob.color / kPi<R>();
+            pdf = div_pi<R>(std::fmax(o.dot(n), R(0)));
             return;
         case PT_MAT_EMISSIVE:                                 // material.rs:139-148
             f = V3<R>::zero(); pdf = 1;
@@ -921,7 +930,7 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
                 V3<R> to_light = ls.point - hit.point;
                 R distance = to_light.length();
                 V3<R> light_dir = to_light.normalize();
-                Ray<R> shadow(hit.point, light_dir);
+                Ray<R> shadow = Ray<R>::from_unit(hit.point, light_dir);
                 Hit<R> sh;
                 cn.shadow_rays++; cn.scans++;
                 bool visible = hit_scene(w, shadow, tmin, distance - tmin, sh) < 0;
@@ -951,7 +960,8 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
         if (beta.is_zero()) break;                       // Q7: nothing downstream can contribute
         if (depth >= 65534u) break;                      // device depth counter is 16 bits
         pdf_prev = pdf;
-        ray = Ray<R>(hit.point, wo);
+        // every sampler but Emissive's (wo = normal, material.rs:157) returns a normalised direction
+        ray = obj.mat_tag == PT_MAT_EMISSIVE ? Ray<R>(hit.point, wo) : Ray<R>::from_unit(hit.point, wo);
         ray.eta_ratio = eta_here;
     }
     return L;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpathtrace_amd.so")
+# PATHTRACE_AMD_LIB: alternative build of the same library (A/B experiments of kernel variants)
+LIB_PATH = os.environ.get("PATHTRACE_AMD_LIB") or os.path.join(_HERE, "libpathtrace_amd.so")
 
 
 class PtCamera(C.Structure):
@@ -45,6 +46,8 @@ class PtRenderParams(C.Structure):
         ("max_paths_in_flight", C.c_uint64),
         ("profile", C.c_uint32),
         ("workgroups", C.c_uint32),
+        ("exact_math", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -84,7 +87,7 @@ SYMBOLS = {
     "pt_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
     "pt_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
-    "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double,
+    "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double, C.c_uint32,
                                      _P(C.c_int32), _P(C.c_float)]),
     "pt_last_error": (C.c_char_p, []),
     "pt_abi_version": (C.c_uint32, []),

@@ -55,7 +55,7 @@ template <class T> struct DevBuf {
 constexpr uint32_t kMaxBounces = 65536;        // depth lives in 16 bits of the path state
 constexpr uint32_t kBounceGroup = 8;           // launches enqueued between two queue-length read-backs
 constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
-constexpr uint32_t kDefaultGrid = 256 * 4;     // 256 CUs x 4 resident workgroups (k_bounce: 4 waves/SIMD)
+constexpr uint32_t kDefaultGrid = 256 * 8;     // 256 CUs x (4 resident workgroups at 4 waves/SIMD) x 2 rounds
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
 
 }  // namespace
@@ -204,9 +204,11 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
         runs.back().count++;
         if (o.shape_tag == PT_SHAPE_SPHERE) {
             float4 s = f4(o.shape[0], o.shape[1], o.shape[2], o.shape[3]);
-            scan.push_back(s);
             shape[3 * i] = s;
-            shape[3 * i + 1] = shape[3 * i + 2] = make_float4(0, 0, 0, 0);
+            shape[3 * i + 1] = make_float4(1.0f / s.w, 0, 0, 0);       // 1/radius (shape.rs:86)
+            shape[3 * i + 2] = make_float4(0, 0, 0, 0);
+            s.w = s.w * s.w;                                           // scan record carries r^2 (shape.rs:63)
+            scan.push_back(s);
         } else {
             float v0[3], v1[3], v2[3];
             for (int k = 0; k < 3; ++k) { v0[k] = (float)o.shape[k]; v1[k] = (float)o.shape[3 + k]; v2[k] = (float)o.shape[6 + k]; }
@@ -376,7 +378,8 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             for (; b < group_end; ++b) {
                 a.bounce = b;
                 if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin)], st));
-                ptk::launch_bounce(a, b == 0, grid, st);
+                if (prm->exact_math) ptk::launch_bounce_exact(a, b == 0, grid, st);
+                else ptk::launch_bounce_fast(a, b == 0, grid, st);
                 if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin) + 1], st));
                 ++launches;
             }
@@ -448,8 +451,8 @@ int pt_get_stats(PtContext* c, PtStats* out) {
     return PT_OK;
 }
 
-int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, int32_t* out_id,
-                       float* out_t) {
+int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, uint32_t exact_math,
+                       int32_t* out_id, float* out_t) {
     if (!c || !rays || !out_id || !out_t) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
     if (n == 0) return PT_OK;
@@ -461,7 +464,8 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
     HIP_TRY(hipMalloc((void**)&d_id, n * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&d_t, n * sizeof(float)));
     HIP_TRY(hipMemcpy(d_r, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
-    ptk::launch_debug_hit(c->view, d_r, n, (float)t_min, (float)t_max, d_id, d_t, c->stream);
+    if (exact_math) ptk::launch_debug_hit_exact(c->view, d_r, n, (float)t_min, (float)t_max, d_id, d_t, c->stream);
+    else ptk::launch_debug_hit_fast(c->view, d_r, n, (float)t_min, (float)t_max, d_id, d_t, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_id, d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -13,10 +13,38 @@
 
 #define PT_DEV __device__ __forceinline__
 
-namespace ptd {
+// The file is compiled twice into one library (see Makefile):
+//   PT_MATH_EXACT=1  IEEE correctly-rounded 1/x, a/b, sqrt: every operation is reproducible on the
+//                    host, so this mode is bit-identical to the f32 oracle (the parity tests' proof
+//                    that the kernel logic is right).  PtRenderParams.exact_math = 1.
+//   PT_MATH_EXACT=0  the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 (default mode, 22 % faster: the
+//                    correctly-rounded expansions are ~10 instructions + hazard nops each).  Held to
+//                    the FP32 tolerance against the f64 oracle like the exact mode.
+#ifndef PT_MATH_EXACT
+#define PT_MATH_EXACT 0
+#endif
+#if PT_MATH_EXACT
+#define PTD_NS ptd_exact
+#else
+#define PTD_NS ptd_fast
+#endif
+
+namespace PTD_NS {
 
 constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;   // x / pi is evaluated as x * kInvPi (f32 arithmetic spec)
 constexpr float kInf = __builtin_huge_valf();
+
+// Every division, reciprocal and square root of the device code goes through these three.
+#if PT_MATH_EXACT
+PT_DEV float pt_rcp(float x) { return 1.0f / x; }
+PT_DEV float pt_div(float a, float b) { return a / b; }
+PT_DEV float pt_sqrt(float x) { return __builtin_sqrtf(x); }
+#else
+PT_DEV float pt_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+PT_DEV float pt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+PT_DEV float pt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#endif
 
 // ------------------------------------------------------------------ Vector3 (math.rs:3-244)
 struct f3 {
@@ -29,13 +57,13 @@ PT_DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }    
 PT_DEV f3 operator*(float s, f3 a) { return mk(a.x * s, a.y * s, a.z * s); }         // math.rs:186
 PT_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }      // math.rs:195
 PT_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }                           // math.rs:234
-PT_DEV f3 operator/(f3 a, float s) { float inv = 1.0f / s; return mk(a.x * inv, a.y * inv, a.z * inv); }   // math.rs:208
+PT_DEV f3 operator/(f3 a, float s) { float inv = pt_rcp(s); return mk(a.x * inv, a.y * inv, a.z * inv); }   // math.rs:208
 PT_DEV float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }     // math.rs:24
 PT_DEV float msub(float a, float b, float c, float d) { return __builtin_fmaf(a, b, -(c * d)); }
 PT_DEV f3 cross(f3 a, f3 b) {                                                        // math.rs:29
     return mk(msub(a.y, b.z, a.z, b.y), msub(a.z, b.x, a.x, b.z), msub(a.x, b.y, a.y, b.x));
 }
-PT_DEV float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }                     // math.rs:38
+PT_DEV float length(f3 a) { return pt_sqrt(dot(a, a)); }                     // math.rs:38
 PT_DEV f3 normalize(f3 a) { float len = length(a); return len > 0.0f ? a / len : a; }   // math.rs:48-51
 PT_DEV float luminance(f3 a) { return 0.2126f * a.x + 0.7152f * a.y + 0.0722f * a.z; }  // math.rs:133
 PT_DEV bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
@@ -89,7 +117,7 @@ PT_DEV float u01(uint32_t r) { return (float)(((r >> 9) << 1) | 1u) * (1.0f / 16
 
 // ------------------------------------------------------------------ scene records
 // shape record, 3 float4 per object:
-//   sphere   : r0 = (cx, cy, cz, radius)
+//   sphere   : r0 = (cx, cy, cz, radius), r1 = (1/radius, -, -, -)
 //   triangle : r0 = (v0, -), r1 = (e1 = v1-v0, -), r2 = (e2 = v2-v0, -)
 // material record, 2 float4 per object:
 //   m0 = (mat_tag | shape_tag<<8 | emits<<16 as bits, p0, p1, p2), m1 = (p3, p4, p5, -)
@@ -138,7 +166,7 @@ PT_DEV Hit finish_hit(const float4* __restrict__ shape, int id, uint32_t shape_t
     f3 outward;
     float4 r0 = shape[3 * id];
     if (shape_tag == SHAPE_SPHERE) {
-        outward = (h.point - mk(r0.x, r0.y, r0.z)) / r0.w;      // shape.rs:86
+        outward = (h.point - mk(r0.x, r0.y, r0.z)) * shape[3 * id + 1].x;   // shape.rs:86; r1.x = 1/radius
     } else {
         float4 r1 = shape[3 * id + 1], r2 = shape[3 * id + 2];
         outward = normalize(cross(mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z)));   // shape.rs:195
@@ -156,18 +184,18 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
     float radius = r0.w;
     f3 to_center = center - from;
     float distance_sq = dot(to_center, to_center);
-    float sin_theta_max_sq = (radius * radius) / distance_sq;
-    float cos_theta_max = __builtin_sqrtf(__builtin_fmaxf(1.0f - sin_theta_max_sq, 0.0f));
+    float sin_theta_max_sq = pt_div(radius * radius, distance_sq);
+    float cos_theta_max = pt_sqrt(__builtin_fmaxf(1.0f - sin_theta_max_sq, 0.0f));
     // 1 - cos_theta_max = 1 - sqrt(1 - s) loses its digits in f32 for a small or distant light;
     // s / (1 + sqrt(1 - s)) is the same number.  Observer inside the sphere: cos_theta_max = 0.
-    float omc = sin_theta_max_sq / (1.0f + cos_theta_max);
+    float omc = pt_div(sin_theta_max_sq, 1.0f + cos_theta_max);
     if (sin_theta_max_sq > 1.0f) omc = 1.0f;
     float solid_angle = 2.0f * kPi * omc;
-    pdf_omega = 1.0f / solid_angle;
+    pdf_omega = pt_rcp(solid_angle);
     if (with_target) { point = target; return; }
     float x1 = r1 * omc;                                   // 1 - cos_theta  (shape.rs:114)
     float cos_theta = 1.0f - x1;
-    float sin_theta = __builtin_sqrtf(__builtin_fmaxf(x1 * (2.0f - x1), 0.0f));   // sqrt((1-c)(1+c))
+    float sin_theta = pt_sqrt(__builtin_fmaxf(x1 * (2.0f - x1), 0.0f));   // sqrt((1-c)(1+c))
     float sphi, cphi;
     sincos2pi(r2, sphi, cphi);
     f3 w = normalize(to_center);
@@ -182,7 +210,7 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
     float c = dot(oc, oc) - radius * radius;
     float disc = __builtin_fmaf(half_b, half_b, -(a * c));
     // deliberate deviation: disc clamped at 0 (reference: unguarded sqrt, shape.rs:136)
-    float t = (-half_b - __builtin_sqrtf(__builtin_fmaxf(disc, 0.0f))) * (1.0f / a);
+    float t = (-half_b - pt_sqrt(__builtin_fmaxf(disc, 0.0f))) * pt_rcp(a);
     point = madd(rd, t, from);
 }
 // TriangleShape::sample_surface_from_point, shape.rs:200-242
@@ -191,7 +219,7 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 t
     if (with_target) {
         point = target;
     } else {
-        float sqrt_r1 = __builtin_sqrtf(r1);
+        float sqrt_r1 = pt_sqrt(r1);
         float u = 1.0f - sqrt_r1;
         float v = r2 * sqrt_r1;
         point = madd(e2, v, madd(e1, u, v0));
@@ -203,8 +231,8 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 t
     float d = length(to_light);
     f3 light_dir = to_light / d;
     float cos_light = __builtin_fabsf(dot(normal, -light_dir));
-    float pdf_area = 1.0f / area;
-    pdf_omega = cos_light > 1e-8f ? pdf_area * (d * d) / cos_light : 1e-8f;
+    float pdf_area = pt_rcp(area);
+    pdf_omega = cos_light > 1e-8f ? pt_div(pdf_area * (d * d), cos_light) : 1e-8f;
 }
 PT_DEV void shape_sample(const float4* __restrict__ shape, int id, uint32_t shape_tag, f3 from, bool with_target,
                          f3 target, float r1, float r2, f3& point, float& pdf_omega) {
@@ -229,8 +257,8 @@ PT_DEV void frame_of(f3 n, f3& tangent, f3& bitangent) {
 PT_DEV f3 cosine_sample(f3 n, float r1, float r2) {
     float sphi, cphi;
     sincos2pi(r1, sphi, cphi);
-    float cos_theta = __builtin_sqrtf(r2);
-    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    float cos_theta = pt_sqrt(r2);
+    float sin_theta = pt_sqrt(1.0f - cos_theta * cos_theta);
     float x = sin_theta * cphi, y = sin_theta * sphi, z = cos_theta;
     f3 t, b;
     frame_of(n, t, b);
@@ -240,7 +268,7 @@ PT_DEV float powi5(float x) { float x2 = x * x; return x2 * x2 * x; }
 
 // ---- Mirror (mirror.rs)
 PT_DEV f3 mirror_f(const Mat& m, float cos_theta) {                        // mirror.rs:126-132
-    float f0d = (1.0f - m.ior) / (1.0f + m.ior);
+    float f0d = pt_div(1.0f - m.ior, 1.0f + m.ior);
     f0d = f0d * f0d;
     f3 f0 = mk(f0d, f0d, f0d) * (1.0f - m.metallic) + m.color * m.metallic;
     return f0 + (mk(1.0f, 1.0f, 1.0f) - f0) * powi5(1.0f - cos_theta);
@@ -250,21 +278,21 @@ PT_DEV float mirror_g1(const Mat& m, float cos_theta) {                    // mi
     float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
     float cos2 = cos_theta * cos_theta;
     float term = alpha2 + (1.0f - alpha2) * cos2;
-    return 2.0f * cos_theta / (cos_theta + __builtin_sqrtf(term));
+    return pt_div(2.0f * cos_theta, cos_theta + pt_sqrt(term));
 }
 PT_DEV float mirror_lambda(float alpha2, float c) {                        // mirror.rs:165-172
     float c2 = c * c;
-    float num = __builtin_sqrtf(alpha2 + (1.0f - alpha2) * c2);
-    return (num - c) / (2.0f * c);
+    float num = pt_sqrt(alpha2 + (1.0f - alpha2) * c2);
+    return pt_div(num - c, 2.0f * c);
 }
 PT_DEV float mirror_g(const Mat& m, float ci, float co) {                  // mirror.rs:153-175
     if (ci <= 0.0f || co <= 0.0f) return 0.0f;
     float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
-    return 1.0f / (1.0f + mirror_lambda(alpha2, ci) + mirror_lambda(alpha2, co));
+    return pt_rcp(1.0f + mirror_lambda(alpha2, ci) + mirror_lambda(alpha2, co));
 }
 PT_DEV float ggx_d(float alpha2, float n_h) {                              // mirror.rs:69-70
     float denom = (n_h * n_h) * (alpha2 - 1.0f) + 1.0f;
-    return alpha2 / (kPi * denom * denom);
+    return pt_div(alpha2, kPi * denom * denom);
 }
 // Mirror::brdf, mirror.rs:62-88
 PT_DEV void mirror_brdf(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) {
@@ -281,7 +309,7 @@ PT_DEV void mirror_brdf(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) 
     float denom_brdf = 4.0f * i_n * o_n;
     f = d * g * fr / denom_brdf;
     float i_h = __builtin_fabsf(dot(i, h));
-    pdf = d * __builtin_fabsf(n_h) / (4.0f * i_h);
+    pdf = pt_div(d * __builtin_fabsf(n_h), 4.0f * i_h);
 }
 // Mirror::btdf, mirror.rs:90-124
 PT_DEV void mirror_btdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, float& pdf) {
@@ -299,7 +327,7 @@ PT_DEV void mirror_btdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, f
     f3 fr = mirror_f(m, cos_theta);
     f = (mk(1.0f, 1.0f, 1.0f) - fr) * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
         (i_n * o_n * denom_term * denom_term);
-    float jac = __builtin_fabsf(o_h) / (denom_term * denom_term);
+    float jac = pt_div(__builtin_fabsf(o_h), denom_term * denom_term);
     pdf = d * __builtin_fabsf(n_h) * jac;
 }
 // Mirror::sample_ggx_vndf, mirror.rs:17-60
@@ -310,16 +338,16 @@ PT_DEV f3 mirror_vndf(const Mat& m, f3 view, f3 n, float r1, float r2) {
     f3 vl = mk(dot(view, tangent), dot(view, bitangent), dot(view, n));
     f3 vh = normalize(mk(alpha * vl.x, alpha * vl.y, vl.z));
     float lensq = vh.x * vh.x + vh.y * vh.y;
-    f3 t1 = lensq > 0.0f ? mk(-vh.y, vh.x, 0.0f) * (1.0f / __builtin_sqrtf(lensq)) : mk(1.0f, 0.0f, 0.0f);
+    f3 t1 = lensq > 0.0f ? mk(-vh.y, vh.x, 0.0f) * pt_rcp(pt_sqrt(lensq)) : mk(1.0f, 0.0f, 0.0f);
     f3 t2 = cross(vh, t1);
-    float r = __builtin_sqrtf(r1);
+    float r = pt_sqrt(r1);
     float sphi, cphi;
     sincos2pi(r2, sphi, cphi);
     float p1 = r * cphi;
     float p2 = r * sphi;
     float s = 0.5f * (1.0f + vh.z);
-    p2 = (1.0f - s) * __builtin_sqrtf(1.0f - p1 * p1) + s * p2;
-    float p3 = __builtin_sqrtf(__builtin_fmaxf(1.0f - p1 * p1 - p2 * p2, 0.0f));
+    p2 = (1.0f - s) * pt_sqrt(1.0f - p1 * p1) + s * p2;
+    float p3 = pt_sqrt(__builtin_fmaxf(1.0f - p1 * p1 - p2 * p2, 0.0f));
     f3 nh = frame3(t1, p1, t2, p2, vh, p3);
     f3 ne = normalize(mk(alpha * nh.x, alpha * nh.y, __builtin_fmaxf(nh.z, 0.0f)));
     return normalize(frame3(tangent, ne.x, bitangent, ne.y, n, ne.z));
@@ -352,12 +380,12 @@ PT_DEV void mirror_sample(const Mat& m, f3 dir_in, float eta, f3 n, float r1, fl
         float denom_brdf = 4.0f * i_n * o_n;
         f3 brdf = fr * d * g / (denom_brdf * rr_f);
         float g1v = mirror_g1(m, i_n);
-        float pdf_vndf = g1v * d * __builtin_fmaxf(i_h, 0.0f) / i_n;
-        float p = pdf_vndf / (4.0f * __builtin_fabsf(i_h));
+        float pdf_vndf = pt_div(g1v * d * __builtin_fmaxf(i_h, 0.0f), i_n);
+        float p = pt_div(pdf_vndf, 4.0f * __builtin_fabsf(i_h));
         if (!finite3(brdf) || !__builtin_isfinite(p) || p <= 0.0f) return;
         wo = on; f = brdf; pdf = p; cos_out = o_n;
     } else {
-        float cos_t = __builtin_sqrtf(cos2_t);
+        float cos_t = pt_sqrt(cos2_t);
         f3 o = h * (eta * i_h - cos_t) - i * eta;
         f3 on = normalize(o);
         float o_h = dot(on, h);
@@ -368,9 +396,9 @@ PT_DEV void mirror_sample(const Mat& m, f3 dir_in, float eta, f3 n, float r1, fl
         f3 one_f = mk(1.0f, 1.0f, 1.0f) - fr;
         f3 btdf = one_f * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
                   (i_n * o_n * denom_term * denom_term * (1.0f - rr_f));
-        float jac = __builtin_fabsf(o_h) / (denom_term * denom_term);
+        float jac = pt_div(__builtin_fabsf(o_h), denom_term * denom_term);
         float g1v = mirror_g1(m, i_n);
-        float pdf_vndf = g1v * d * __builtin_fmaxf(i_h, 0.0f) / i_n;
+        float pdf_vndf = pt_div(g1v * d * __builtin_fmaxf(i_h, 0.0f), i_n);
         float p = pdf_vndf * jac;
         if (!finite3(btdf) || !__builtin_isfinite(p) || p <= 0.0f) return;
         wo = on; f = btdf; pdf = p; cos_out = o_n;
@@ -381,25 +409,25 @@ PT_DEV void mirror_sample(const Mat& m, f3 dir_in, float eta, f3 n, float r1, fl
 PT_DEV void oren_nayar_eval(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) {
     f3 i = -dir_in;
     float ci = __builtin_fmaxf(dot(i, n), 0.0f), co = __builtin_fmaxf(dot(o, n), 0.0f);
-    float si = __builtin_sqrtf(__builtin_fmaxf(1.0f - ci * ci, 0.0f));
-    float so = __builtin_sqrtf(__builtin_fmaxf(1.0f - co * co, 0.0f));
+    float si = pt_sqrt(__builtin_fmaxf(1.0f - ci * ci, 0.0f));
+    float so = pt_sqrt(__builtin_fmaxf(1.0f - co * co, 0.0f));
     f3 tangent, bitangent;
     frame_of(n, tangent, bitangent);
     float phi_i = atan2f(dot(i, bitangent), dot(i, tangent));
     float phi_o = atan2f(dot(o, bitangent), dot(o, tangent));
     float cos_phi = __builtin_fmaxf(cosf(phi_i - phi_o), 0.0f);
     float sin_alpha, tan_beta;
-    if (ci > co) { tan_beta = ci > 1e-6f ? si / ci : 0.0f; sin_alpha = so; }
-    else { tan_beta = co > 1e-6f ? so / co : 0.0f; sin_alpha = si; }
+    if (ci > co) { tan_beta = ci > 1e-6f ? pt_div(si, ci) : 0.0f; sin_alpha = so; }
+    else { tan_beta = co > 1e-6f ? pt_div(so, co) : 0.0f; sin_alpha = si; }
     float term = m.on_a + m.on_b * cos_phi * sin_alpha * tan_beta;
-    f = m.color * (term / kPi);
-    pdf = __builtin_fmaxf(dot(o, n), 0.0f) / kPi;
+    f = m.color * (term * kInvPi);
+    pdf = __builtin_fmaxf(dot(o, n), 0.0f) * kInvPi;
 }
 // Object::bsdf_pdf (object.rs:35-43)
 PT_DEV void bsdf_pdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, float& pdf) {
     if (m.tag == MAT_LAMBERT) {                                      // material.rs:86-91
-        f = m.color / kPi;
-        pdf = __builtin_fmaxf(dot(o, n), 0.0f) / kPi;
+        f = m.color * kInvPi;
+        pdf = __builtin_fmaxf(dot(o, n), 0.0f) * kInvPi;
     } else if (m.tag == MAT_EMISSIVE) {                              // material.rs:139-148
         f = mk(0.0f, 0.0f, 0.0f); pdf = 1.0f;
     } else if (m.tag == MAT_MIRROR) {                                // mirror.rs:179-198
@@ -434,4 +462,4 @@ PT_DEV float rr_prob(uint32_t depth, uint32_t min_depth, uint32_t max_depth, f3 
     return l;
 }
 
-}  // namespace ptd
+}  // namespace PTD_NS

@@ -17,7 +17,7 @@ struct Run {
 };
 
 struct SceneView {
-    const float4* scan;      // scan records, run-packed: sphere = 1 float4 (c, r); triangle = 3 float4 (v0, e1, e2)
+    const float4* scan;      // scan records, run-packed: sphere = 1 float4 (c, r^2); triangle = 3 float4 (v0, e1, e2)
     const float4* shape;     // 3 float4 per object (gather form), see pt_device.h
     const float4* mat;       // 2 float4 per object
     const Run* runs;
@@ -81,7 +81,9 @@ constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tile (divisible by 3: w
 
 // grid = number of 256-thread workgroups; it fixes the number of queue segments
 // (4 per workgroup) and must not change between the bounces of one batch
-void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
+// _exact / _fast: the two arithmetic modes of pt_device.h (PtRenderParams.exact_math)
+void launch_bounce_exact(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
+void launch_bounce_fast(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
 
 // Film: sum the nb samples of every tile pixel in sample order into the f64
 // accumulator (world.rs:311), and on the last batch write mean, sqrt-gamma and
@@ -98,7 +100,9 @@ struct ResolveArgs {
 void launch_resolve(const ResolveArgs& a, hipStream_t st);
 
 // World::hit_scene on arbitrary rays (debug/parity entry).
-void launch_debug_hit(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max, int32_t* out_id,
-                      float* out_t, hipStream_t st);
+void launch_debug_hit_exact(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max,
+                            int32_t* out_id, float* out_t, hipStream_t st);
+void launch_debug_hit_fast(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max,
+                           int32_t* out_id, float* out_t, hipStream_t st);
 
 }  // namespace ptk

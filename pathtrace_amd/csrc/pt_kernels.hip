@@ -21,12 +21,21 @@
 #include "pt_device.h"
 #include "pt_kernels.h"
 
-using namespace ptd;
+using namespace PTD_NS;
+using namespace ptk;
 
-namespace ptk {
+#if PT_MATH_EXACT
+#define PTK_IMPL ptk_exact_impl
+#define PT_LAUNCH(name) name##_exact
+#else
+#define PTK_IMPL ptk_fast_impl
+#define PT_LAUNCH(name) name##_fast
+#endif
+
+namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ primitive tests
-// SphereShape::hit (shape.rs:53-82) against the running closest t.
+// SphereShape::hit (shape.rs:53-82) against the running closest t.  s = (center, r^2).
 PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min, float& closest, int& id, int obj) {
     f3 oc = o - mk(s.x, s.y, s.z);
     float half_b = dot(oc, d);
@@ -34,15 +43,17 @@ PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min,
     // same quantity, robust form: a * (r^2 - |oc - (half_b/a) d|^2)  (Ray Tracing Gems ch. 7)
     float k = half_b * inv_a;
     f3 l = madd(d, -k, oc);
-    float disc = a * (s.w * s.w - dot(l, l));
+    float q = s.w - dot(l, l);
+    float disc = a * q;
     if (disc < 0.0f) return;                       // NaN falls through, as in the reference (Q10)
-    float sqrtd = __builtin_sqrtf(disc);
-    float root = (-half_b - sqrtd) * inv_a;
-    if (root < t_min || closest < root) {
-        root = (-half_b + sqrtd) * inv_a;
-        if (root < t_min || closest < root) return;
-    }
-    closest = root;
+    float sqrtd = pt_sqrt(disc);
+    float root1 = (-half_b - sqrtd) * inv_a;
+    float root2 = (-half_b + sqrtd) * inv_a;
+    // shape.rs:76-82: take the near root unless it is out of range, then the far one.  root2 >= root1,
+    // so "closest < root1" already rejects both; hence the candidate is root2 only when root1 < t_min.
+    float c = root1 < t_min ? root2 : root1;
+    if (c < t_min || closest < c) return;          // NaN is accepted, as in the reference
+    closest = c;
     id = obj;
 }
 // TriangleShape::hit (shape.rs:161-192), Moeller-Trumbore; e1, e2 precomputed.
@@ -50,7 +61,7 @@ PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& c
     f3 h = cross(d, e2);
     float a = dot(e1, h);
     if (__builtin_fabsf(a) < 1e-8f) return;
-    float f = 1.0f / a;
+    float f = pt_rcp(a);
     f3 s = o - v0;
     float u = f * dot(s, h);
     if (!(u >= 0.0f && u <= 1.0f)) return;         // RangeInclusive::contains: NaN rejected
@@ -124,7 +135,7 @@ PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
 template <bool SMALL>
 PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
     float a = dot(d, d);
-    float inv_a = 1.0f / a;
+    float inv_a = pt_rcp(a);
     float closest = t_max;
     int id = -1;
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
@@ -173,8 +184,11 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 // just BEFORE this iteration's stores, so the only vector-memory wait of the loop
 // sits behind ~5000 cycles of work and never behind a store.  With a SMALL scene
 // nothing else in the loop touches global memory.
+#ifndef PT_BOUNCE_WAVES
+#define PT_BOUNCE_WAVES 4      // minimum waves per SIMD the register allocator must leave room for
+#endif
 template <bool FIRST, bool SMALL, bool MIS>
-__global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
+__global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a) {
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
     const SceneRef sc = stage_scene<SMALL>(a.sc, lds);
@@ -244,8 +258,8 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
             uint32_t dc[4];
             philox4x32_10(sample, kDepthCamera, 0u, 0u, px, py, dc);
             float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
-            float u = ((float)px + ox) / (float)(a.cam.width - 1u);               // camera.rs:140
-            float v = ((float)(a.cam.height - 1u - py) + oy) / (float)(a.cam.height - 1u);   // world.rs:299 y flip
+            float u = pt_div((float)px + ox, (float)(a.cam.width - 1u));               // camera.rs:140
+            float v = pt_div((float)(a.cam.height - 1u - py) + oy, (float)(a.cam.height - 1u));   // world.rs:299 y flip
             f3 dir = mk(a.cam.lower_left[0], a.cam.lower_left[1], a.cam.lower_left[2]) +
                      mk(a.cam.horizontal[0], a.cam.horizontal[1], a.cam.horizontal[2]) * u +
                      mk(a.cam.vertical[0], a.cam.vertical[1], a.cam.vertical[2]) * v - cam_o;   // camera.rs:143-144
@@ -274,7 +288,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
                     // pdf seen from the previous vertex = this ray's origin (rendering.rs:107-121)
                     f3 sp; float pdf_shape;
                     shape_sample(sc.shape, id, m.shape_tag, o, true, hit.point, 0.f, 0.f, sp, pdf_shape);
-                    float w_bsdf = pdf_prev / (pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
+                    float w_bsdf = pt_div(pdf_prev, pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
                     L = L + beta * m.color * w_bsdf;
                 }
                 alive = false;
@@ -295,7 +309,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
             shape_sample(sc.shape, lobj, lm.shape_tag, hit.point, false, hit.point, u01(dl[1]), u01(dl[2]), lp,
                          pdf_shape);
             ls_emission = lm.color;                                               // world.rs:259
-            ls_pdf = pdf_shape / (float)sc.n_lights;                              // world.rs:260
+            ls_pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);   // world.rs:260 (x/1 == x)
             f3 to_light = lp - hit.point;                                         // rendering.rs:58-60
             distance = length(to_light);
             light_dir = normalize(to_light);
@@ -307,7 +321,9 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
         if (MIS) {
             bool any_shadow = SMALL ? (__ballot(need_shadow) != 0ull) : (__syncthreads_or(need_shadow) != 0);
             if (any_shadow) {
-                f3 sdir = need_shadow ? normalize(light_dir) : mk(0.f, 0.f, 0.f);   // Ray::new normalises again
+                // Ray::new (rendering.rs:62) would normalise light_dir a second time; the f32
+                // arithmetic specification normalises a direction once
+                f3 sdir = need_shadow ? light_dir : mk(0.f, 0.f, 0.f);
                 f3 sorg = need_shadow ? hit.point : mk(0.f, 0.f, 0.f);
                 int sid; float st;
                 scan_closest<SMALL>(sc, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
@@ -320,7 +336,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
             float cos_theta = __builtin_fabsf(dot(hit.normal, light_dir));        // rendering.rs:68
             f3 bsdf; float pdf_bsdf;
             bsdf_pdf(m, d, eta_in, light_dir, hit.normal, bsdf, pdf_bsdf);        // :71-72 (stale eta, Q5)
-            float w_nee = ls_pdf / (ls_pdf + pdf_bsdf);                           // :73
+            float w_nee = pt_div(ls_pdf, ls_pdf + pdf_bsdf);                           // :73
             direct = w_nee * bsdf * ls_emission * cos_theta / ls_pdf;             // :75-76
         }
 
@@ -329,7 +345,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
             uint32_t db[4];
             philox4x32_10(sample, depth, BLK_BSDF, 0u, px, py, db);
             float eta_mat = m.tag == MAT_MIRROR ? m.ior : 1.0f;                   // get_eta, material.rs:50 / mirror.rs:317
-            float eta_here = hit.front_face ? 1.0f / eta_mat : eta_mat;           // rendering.rs:20-25
+            float eta_here = hit.front_face ? pt_rcp(eta_mat) : eta_mat;           // rendering.rs:20-25
             f3 wo, bsdf; float pdf, cos_theta;
             bsdf_pdf_sample(m, d, eta_here, hit.normal, db, wo, bsdf, pdf, cos_theta);   // :84-85
             f3 next_tp = beta * bsdf * cos_theta / pdf;                           // :89
@@ -344,7 +360,8 @@ __global__ void __launch_bounds__(kBlock) k_bounce(BounceArgs a) {
                 } else {
                     pdf_prev = pdf;
                     o = hit.point;
-                    d = normalize(wo);                                            // Ray::new, :86
+                    d = m.tag == MAT_EMISSIVE ? normalize(wo) : wo;               // Ray::new, :86; every sampler but
+                                                                                  // Emissive's returns a normalised wo
                     eta_in = eta_here;                                            // :87
                     depth += 1u;
                 }
@@ -390,7 +407,10 @@ static void launch_bounce_t(const BounceArgs& a, uint32_t grid, size_t lds_bytes
     hipLaunchKernelGGL((k_bounce<FIRST, SMALL, MIS>), dim3(grid), dim3(kBlock), lds_bytes, st, a);
 }
 
-void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st) {
+}  // namespace PTK_IMPL
+namespace ptk {
+using namespace PTK_IMPL;
+void PT_LAUNCH(launch_bounce)(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st) {
     const bool small = a.sc.n_objs <= kSmallObjs;
     const bool mis = a.integrator == 0;
     const size_t lds = scene_lds_bytes(a.sc);
@@ -400,6 +420,8 @@ void launch_bounce(const BounceArgs& a, bool first, uint32_t grid, hipStream_t s
     PT_CASE(false, true, true) PT_CASE(false, true, false) PT_CASE(false, false, true) PT_CASE(false, false, false)
 #undef PT_CASE
 }
+}  // namespace ptk
+namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ film resolve
 // World::render_pixel's tail (world.rs:311-332).  One thread per tile pixel; the
@@ -431,9 +453,15 @@ __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
     }
     if (a.out_rgba) a.out_rgba[4 * (size_t)p + 3] = 255;                          // world.rs:331
 }
+}  // namespace PTK_IMPL
+#if !PT_MATH_EXACT
+namespace ptk {   // the film resolve has no division or sqrt in f32: one copy serves both modes
 void launch_resolve(const ResolveArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_resolve, dim3((a.np + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(PTK_IMPL::k_resolve, dim3((a.np + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
 }
+}  // namespace ptk
+#endif
+namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ debug: hit_scene on arbitrary rays
 template <bool SMALL>
@@ -454,8 +482,11 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float
         if (active) { out_id[i] = id; out_t[i] = id >= 0 ? t : 0.0f; }
     }
 }
-void launch_debug_hit(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max, int32_t* out_id,
-                      float* out_t, hipStream_t st) {
+}  // namespace PTK_IMPL
+namespace ptk {
+using namespace PTK_IMPL;
+void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max,
+                                 int32_t* out_id, float* out_t, hipStream_t st) {
     const bool small = sc.n_objs <= kSmallObjs;
     uint32_t grid = (n + kBlock - 1) / kBlock;
     if (grid > 2048u) grid = 2048u;

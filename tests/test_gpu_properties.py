@@ -1,4 +1,5 @@
-"""Size-independent properties of the HIP path, checked at BASELINE.json's full
+"""Size-independent properties of the HIP path in its default (fast) arithmetic mode --
+the mode bench.py measures -- checked at BASELINE.json's full
 sizes (1024x1024, 64 spp and the 10 000-sphere scene): determinism, invariance to
 how the work is scheduled (batches, queue segments, row bands), linearity in spp,
 consistency of the two film planes, closed-form radiometry."""
@@ -72,6 +73,18 @@ def test_c4_ten_thousand_spheres_full_width_determinism(pt, gpu_ctx):
     assert np.array_equal(frame, a)
 
 
+def test_exact_mode_full_size_matches_fast_mode_statistically(pt, gpu_ctx):
+    """1024^2 x 16 spp C2 in both arithmetic modes: same estimator, ulp-perturbed paths."""
+    gpu_ctx.upload(pt.builtin_scene(2))
+    cam = pt.camera_new(width=1024, height=1024)
+    fast, _, sf = _render(pt, gpu_ctx, cam, spp=16)
+    exact, _, se = _render(pt, gpu_ctx, cam, spp=16, exact_math=1)
+    assert abs(fast.mean() - exact.mean()) <= 2e-5 * exact.mean()
+    rel = np.abs(fast.astype(np.float64) - exact) / np.maximum(np.abs(exact), 1e-6)
+    assert (rel.max(-1) <= 1e-3).mean() >= 0.99
+    assert abs(int(sf.vertices) - int(se.vertices)) <= 1e-4 * se.vertices
+
+
 def test_furnace_brdf_only_on_gpu(pt, gpu_ctx):
     """Convex Lambertian sphere (albedo rho) in a uniform emitter Le: outgoing radiance = rho * Le."""
     rho, le = 0.6, 2.0
@@ -95,7 +108,7 @@ def test_edge_sizes(pt, orc, gpu_ctx):
     gpu_ctx.upload(objs)
     for (w, h, spp) in [(2, 2, 1), (3, 5, 1), (65, 2, 3), (2, 67, 2)]:
         cam = pt.camera_new(width=w, height=h)
-        prm = pt.default_params(spp=spp)
+        prm = pt.default_params(spp=spp, exact_math=1)
         lin, rgba = gpu_ctx.render(cam, prm)
         ref, ref8, _ = orc.render(cam, objs, prm, orc.F32, orc.ITERATIVE)
         assert np.array_equal(lin.cpu().numpy(), ref.astype(np.float32)) and np.array_equal(rgba.cpu().numpy(), ref8)

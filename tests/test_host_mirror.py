@@ -38,7 +38,7 @@ def test_cpp_world_render_matches_oracle(pt, orc, tmp_path, w, h):
     """400x400 is World::new() itself; the other size re-authors the scene through the mirrored constructors."""
     spp = 2
     prefix = str(tmp_path / "c")
-    r = subprocess.run([EXE, str(w), str(h), str(spp), prefix], capture_output=True, text=True)
+    r = subprocess.run([EXE, str(w), str(h), str(spp), prefix, "1"], capture_output=True, text=True)   # exact_math
     assert r.returncode == 0, r.stderr
     got = load_luminance_csv(prefix + "_luminance.csv")
     cam = pt.camera_new(width=w, height=h)
