@@ -94,7 +94,7 @@ typedef struct {
     /* Wavefront sizing: upper bound on paths resident in HBM at once
      * (0 = library default).                                                  */
     uint64_t max_paths_in_flight;
-    uint32_t profile;        /* 1: time every bounce launch with HIP events    */
+    uint32_t profile;        /* 1: time every path-kernel launch with HIP events */
     /* Workgroups (256 threads) of the persistent bounce grid; every wave owns one
      * private queue segment.  0 = library default (4 per CU).  Results do not
      * depend on it.                                                           */
@@ -113,12 +113,12 @@ typedef struct {
     uint64_t vertices;         /* path vertices processed (iterations of the
                                   per-vertex loop)                 */
     uint64_t shadow_rays;      /* NEE visibility scans                         */
-    uint32_t bounce_launches;  /* bounce-kernel launches                       */
+    uint32_t bounce_launches;  /* path-kernel launches (one per sample batch)  */
     uint32_t batches;          /* sample batches                               */
     uint32_t max_depth_reached;
     uint32_t reserved;
-    double   bounce_kernel_ms; /* sum of HIP-event durations of the bounce
-                                  kernel launches (profile=1), else 0         */
+    double   bounce_kernel_ms; /* sum of HIP-event durations of the path-kernel
+                                  launches (profile=1), else 0                */
     double   total_ms;         /* HIP-event duration of the whole render      */
 } PtStats;
 

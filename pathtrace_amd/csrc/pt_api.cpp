@@ -52,8 +52,6 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-constexpr uint32_t kMaxBounces = 65536;        // depth lives in 16 bits of the path state
-constexpr uint32_t kBounceGroup = 8;           // launches enqueued between two queue-length read-backs
 constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
 constexpr uint32_t kDefaultGrid = 256 * 8;     // 256 CUs x (4 resident workgroups at 4 waves/SIMD) x 2 rounds
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
@@ -73,17 +71,16 @@ struct PtContext {
     // wavefront state
     DevBuf<float4> queue[4];
     DevBuf<float4> lsamp;
-    DevBuf<uint32_t> counters, seg_count;
     DevBuf<unsigned long long> dstats;
     DevBuf<double> film;
     DevBuf<float> host_lin;       // device staging of pt_render_host
     DevBuf<uint8_t> host_rgba;
-    uint32_t* h_counters = nullptr;   // pinned
     unsigned long long* h_dstats = nullptr;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     PtStats stats{};
     bool stats_pending = false;
+    uint32_t profiled_batches = 0;
 };
 
 namespace {
@@ -152,8 +149,7 @@ int pt_context_create(int device, PtContext** out) {
         return fail(PT_ERR_HIP, "hipStreamCreateWithFlags failed");
     }
     c->stream = c->own_stream;
-    if (hipHostMalloc((void**)&c->h_counters, (size_t)(kMaxBounces + 2) * ptk::kCounterShards * sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_dstats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipHostMalloc((void**)&c->h_dstats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
         delete c;
         return fail(PT_ERR_HIP, "context allocation failed");
@@ -168,8 +164,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipStreamSynchronize(c->stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     for (auto& b : c->queue) b.release();
-    c->lsamp.release(); c->counters.release(); c->seg_count.release(); c->dstats.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    c->lsamp.release(); c->dstats.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
     if (c->h_dstats) (void)hipHostFree(c->h_dstats);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -316,23 +311,18 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const uint32_t nw = grid * kWavesPerBlock;
     const uint32_t seg_cap = ((chunks_max + nw - 1) / nw) * 64u;
     const size_t q_slots = (size_t)nw * seg_cap;
-    const size_t n_counter = (size_t)(kMaxBounces + 2) * ptk::kCounterShards;
 
     int rc;
     for (int k = 0; k < 4; ++k)
         if ((rc = c->queue[k].ensure(q_slots))) return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
-    if ((rc = c->counters.ensure(n_counter))) return rc;
-    if ((rc = c->seg_count.ensure(nw))) return rc;
     if ((rc = c->dstats.ensure(8))) return rc;
     if (n_batches > 1 && (rc = c->film.ensure((size_t)np * 3))) return rc;
 
     ptk::BounceArgs a{};
     for (int k = 0; k < 4; ++k) a.q.q[k] = c->queue[k].p;
-    a.seg_count = c->seg_count.p;
     a.seg_cap = seg_cap;
     a.lsamp = c->lsamp.p;
-    a.counters = c->counters.p;
     a.stats = c->dstats.p;
     {   // tile row -> image row without a table (ptk::TileMap)
         const uint32_t br = prm->band_rows ? prm->band_rows : cam->height;
@@ -355,57 +345,19 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const bool profile = prm->profile != 0;
     HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(c->ev_begin, st));
-    double bounce_ms = 0.0;
-    uint64_t vertices = 0;
-    uint32_t launches = 0, max_depth_reached = 0;
+    if (profile && (rc = ensure_events(c, 2 * (size_t)n_batches))) return rc;
 
     for (uint32_t batch = 0; batch < n_batches; ++batch) {
         const uint32_t s0 = batch * nb_max;
         const uint32_t nb = std::min(nb_max, prm->spp - s0);
-        const uint32_t n_first = np * nb;
-        a.n_first = n_first;
+        a.n_first = np * nb;
         a.s_base = prm->spp_offset + s0;
-        uint32_t b = 0;              // next bounce to launch
-        uint64_t entering = n_first; // paths entering bounce b
-        bool drained = false;
-        while (!drained) {
-            const uint32_t group_end = std::min(b + kBounceGroup, kMaxBounces);
-            const uint32_t group_begin = b;
-            // totals of the bounces this group feeds: rows group_begin+1 .. group_end
-            HIP_TRY(hipMemsetAsync(c->counters.p + (size_t)(group_begin + 1) * ptk::kCounterShards, 0,
-                                   (size_t)(group_end - group_begin) * ptk::kCounterShards * sizeof(uint32_t), st));
-            if (profile && (rc = ensure_events(c, 2 * (size_t)(group_end - group_begin)))) return rc;
-            for (; b < group_end; ++b) {
-                a.bounce = b;
-                if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin)], st));
-                if (prm->exact_math) ptk::launch_bounce_exact(a, b == 0, grid, st);
-                else ptk::launch_bounce_fast(a, b == 0, grid, st);
-                if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (b - group_begin) + 1], st));
-                ++launches;
-            }
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(c->h_counters + (size_t)(group_begin + 1) * ptk::kCounterShards,
-                                   c->counters.p + (size_t)(group_begin + 1) * ptk::kCounterShards,
-                                   (size_t)(b - group_begin) * ptk::kCounterShards * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (profile)
-                for (uint32_t k = 0; k < b - group_begin; ++k) {
-                    float ms = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[2 * k], c->ev_pool[2 * k + 1]));
-                    bounce_ms += ms;
-                }
-            // paths entering bounce k: n_first for k = 0, else the sharded total written by bounce k-1
-            for (uint32_t k = group_begin; k < b; ++k) {
-                vertices += entering;
-                if (entering > 0 && k > max_depth_reached) max_depth_reached = k;
-                uint64_t next = 0;
-                for (uint32_t sh = 0; sh < ptk::kCounterShards; ++sh)
-                    next += c->h_counters[(size_t)(k + 1) * ptk::kCounterShards + sh];
-                entering = next;
-            }
-            if (entering == 0 || b >= kMaxBounces) drained = true;
-        }
+        // one launch traces the batch's paths to their end (every bounce), see k_paths
+        if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * batch], st));
+        if (prm->exact_math) ptk::launch_paths_exact(a, grid, st);
+        else ptk::launch_paths_fast(a, grid, st);
+        if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * batch + 1], st));
+        HIP_TRY(hipGetLastError());
         ptk::ResolveArgs r{};
         r.lsamp = c->lsamp.p;
         r.film = c->film.p;
@@ -421,11 +373,9 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     HIP_TRY(hipEventRecord(c->ev_end, st));
     HIP_TRY(hipMemcpyAsync(c->h_dstats, c->dstats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     c->stats.samples = (uint64_t)np * prm->spp;
-    c->stats.vertices = vertices;
-    c->stats.bounce_launches = launches;
+    c->stats.bounce_launches = n_batches;
     c->stats.batches = n_batches;
-    c->stats.max_depth_reached = max_depth_reached;
-    c->stats.bounce_kernel_ms = bounce_ms;
+    c->profiled_batches = profile ? n_batches : 0;
     c->stats_pending = true;
     return PT_OK;
 }
@@ -437,7 +387,13 @@ int pt_sync(PtContext* c) {
     if (c->stats_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.total_ms = ms;
+        double kms = 0.0;
+        for (uint32_t b = 0; b < c->profiled_batches; ++b)
+            if (hipEventElapsedTime(&ms, c->ev_pool[2 * b], c->ev_pool[2 * b + 1]) == hipSuccess) kms += ms;
+        c->stats.bounce_kernel_ms = kms;
         c->stats.shadow_rays = c->h_dstats[0];
+        c->stats.vertices = c->h_dstats[1];
+        c->stats.max_depth_reached = (uint32_t)c->h_dstats[2];
         c->stats_pending = false;
     }
     return PT_OK;

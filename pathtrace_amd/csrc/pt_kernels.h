@@ -44,8 +44,6 @@ struct Queue {
     float4* q[4];
 };
 
-constexpr uint32_t kCounterShards = 16;
-
 // Row-band tile (include/pathtrace_amd.h): tile row yl -> image row
 //   y = (yl / band_rows) * band_stride + band_first + yl % band_rows
 // with yl / band_rows = umulhi(yl, band_magic) (exact for yl, band_rows < 65536).
@@ -55,16 +53,13 @@ struct TileMap {
 
 struct BounceArgs {
     Queue q;                  // compacted in place, one private segment per wave
-    uint32_t* seg_count;      // [wave] queued paths of the wave's segment (in: this bounce, out: next)
     uint32_t seg_cap;         // slots per segment (multiple of 64)
     float4* lsamp;            // per-path final radiance, index = s_local*np + tile_row*width + x
-    uint32_t* counters;       // counters[b*kCounterShards + s]: sharded total of paths entering bounce b
-    unsigned long long* stats;  // [0] shadow rays
+    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest pass (max)
     TileMap tile;
     SceneView sc;
     CameraF cam;
-    uint32_t bounce;          // b
-    uint32_t n_first;         // paths of the batch (bounce 0 only)
+    uint32_t n_first;         // paths of the batch
     uint32_t np;              // pixels of the tile
     uint32_t s_base;          // sample index of s_local = 0 (spp_offset + batch start)
     uint32_t min_depth, max_depth;
@@ -79,11 +74,11 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kSmallObjs = 128;
 constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tile (divisible by 3: whole triangles)
 
-// grid = number of 256-thread workgroups; it fixes the number of queue segments
-// (4 per workgroup) and must not change between the bounces of one batch
-// _exact / _fast: the two arithmetic modes of pt_device.h (PtRenderParams.exact_math)
-void launch_bounce_exact(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
-void launch_bounce_fast(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st);
+// One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
+// (4 queue segments each).  _exact / _fast: the two arithmetic modes of pt_device.h
+// (PtRenderParams.exact_math).
+void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);
+void launch_paths_fast(const BounceArgs& a, uint32_t grid, hipStream_t st);
 
 // Film: sum the nb samples of every tile pixel in sample order into the f64
 // accumulator (world.rs:311), and on the last batch write mean, sqrt-gamma and

@@ -166,8 +166,8 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
     return q * t.band_stride + t.band_first + (yl - q * t.band_rows);
 }
 
-// ------------------------------------------------------------------ bounce kernel
-// Queue organisation.  The path queue is cut into one private segment per wave
+// ------------------------------------------------------------------ the path kernel
+// Queue organisation.  The path queue is cut into one PRIVATE segment per wave
 // (segment w = slots [w*seg_cap, (w+1)*seg_cap)).  A wave reads its segment 64
 // slots at a time (one coalesced 1 KiB access per plane), advances those paths by
 // one vertex and writes the survivors back INTO THE SAME SEGMENT at its running
@@ -176,8 +176,15 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 // the compaction is in place, needs no second queue and no global atomic.  (A
 // single shared tail counter costs one returning atomic per wave per iteration:
 // measured 59 ms of a 60 ms render at 1024^2 x 64 spp.)
-// Bounce 0 deals 64-path chunks round-robin to the waves (chunk k -> wave k % nw)
-// so that every segment samples the whole image and segments decay alike.
+//
+// Because no wave ever touches another wave's slots, nothing forces the waves to
+// advance bounce by bounce in lockstep: ONE launch runs every bounce of a batch.
+// Each wave loops { pass over its segment = one more vertex for each of its paths }
+// until its segment is empty.  (One launch per bounce cost ~2.5 of 13.2 ms in launch
+// gaps, host polling and under-filled tail launches.)  Pass 0 deals 64-path chunks
+// round-robin to the waves (chunk k -> wave k % nw) and generates the camera rays
+// (Camera::get_ray_with_offset), so every segment samples the whole image and the
+// waves finish together.
 //
 // Memory pipeline of one iteration: the NEXT chunk's state is requested at the top
 // (4 x 16 B per lane in flight during the whole vertex computation) and consumed
@@ -187,8 +194,8 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4      // minimum waves per SIMD the register allocator must leave room for
 #endif
-template <bool FIRST, bool SMALL, bool MIS>
-__global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a) {
+template <bool SMALL, bool MIS>
+__global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a) {
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
     const SceneRef sc = stage_scene<SMALL>(a.sc, lds);
@@ -196,25 +203,31 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (kBlock / 64);
     const uint32_t seg_base = wave * a.seg_cap;
-    const uint32_t n_chunks = (a.n_first + 63u) >> 6;              // bounce 0: 64-path chunks of the batch
-    const uint32_t n_in = FIRST ? 0u : a.seg_count[wave];          // queued paths of this wave
-    uint32_t n_iter = FIRST ? (n_chunks + nw - 1u) / nw : (n_in + 63u) >> 6;
-    if (!SMALL && !FIRST) {
+    const uint32_t n_chunks = (a.n_first + 63u) >> 6;              // pass 0: 64-path chunks of the batch
+    const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+    const uint32_t W = a.cam.width;
+    uint32_t n_in = 0;                     // wave-uniform: queued paths of this wave's segment
+    uint32_t wave_shadow = 0, wave_vertices = 0, wave_depth = 0;
+
+    for (uint32_t pass = 0;; ++pass) {
+    const bool first = pass == 0u;
+    uint32_t n_iter = first ? (n_chunks + nw - 1u) / nw : (n_in + 63u) >> 6;
+    if (!SMALL) {
         // the tiled scan synchronises the workgroup: every wave runs the longest wave's trip count
+        __syncthreads();
         if (lane == 0u) s_iters[threadIdx.x >> 6] = n_iter;
         __syncthreads();
         uint32_t m = 0;
         for (uint32_t k = 0; k < kBlock / 64; ++k) m = s_iters[k] > m ? s_iters[k] : m;
         n_iter = m;
     }
-    const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
-    const uint32_t W = a.cam.width;
-    uint32_t out_n = 0;          // wave-uniform: survivors written so far
-    uint32_t wave_shadow = 0;
+    if (n_iter == 0u) break;               // SMALL: this wave is done; tiled: the whole workgroup is
+    if (n_in != 0u || first) wave_depth = pass;
+    uint32_t out_n = 0;                    // wave-uniform: survivors written so far in this pass
 
     // state of the next chunk, in flight
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
-    if (!FIRST && lane < n_in) {
+    if (!first && lane < n_in) {
         const uint32_t s0 = seg_base + lane;
         n0 = a.q.q[0][s0]; n1 = a.q.q[1][s0]; n2 = a.q.q[2][s0]; n3 = a.q.q[3][s0];
     }
@@ -225,7 +238,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a
         float pdf_prev = 0.0f, eta_in = 1.0f;
         uint32_t s_local = 0, depth = 0, px = 0, yl = 0, py = 0;
 
-        if (FIRST) {
+        if (first) {
             const uint32_t chunk = it * nw + wave;
             const uint32_t pid = chunk * 64u + lane;
             active = chunk < n_chunks && pid < a.n_first;
@@ -254,7 +267,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a
         py = image_row(a.tile, yl);                  // key of the path's RNG stream = (x, y), main.rs:51
         const uint32_t sample = a.s_base + s_local;
 
-        if (FIRST && active) {
+        if (first && active) {
             uint32_t dc[4];
             philox4x32_10(sample, kDepthCamera, 0u, 0u, px, py, dc);
             float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
@@ -266,6 +279,8 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a
             o = cam_o;
             d = normalize(dir);                                                   // Ray::new, camera.rs:13
         }
+
+        wave_vertices += (uint32_t)__popcll(__ballot(active));
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
@@ -369,7 +384,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a
         }
 
         // ---- the next chunk must have landed before anything is stored (in-place queue)
-        if (!FIRST) {
+        if (!first) {
             asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z),
                          "+v"(n1.w));
             asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z),
@@ -389,11 +404,16 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_bounce(BounceArgs a
         }
         out_n += (uint32_t)__popcll(mask);
     }
+    n_in = out_n;
+    // the next pass reads (from other lanes of this wave) what this pass stored
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (SMALL && n_in == 0u) break;
+    }   // pass loop
     if (lane == 0u) {
-        a.seg_count[wave] = out_n;
-        // per-launch totals for the host (termination test, vertex count): sharded, result unused
-        if (out_n != 0u) atomicAdd(&a.counters[(a.bounce + 1u) * kCounterShards + (wave & (kCounterShards - 1u))], out_n);
+        // totals for the host: shadow rays, vertices (= loop iterations summed over paths), deepest pass
         if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
+        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
+        atomicMax(&a.stats[2], (unsigned long long)wave_depth);
     }
 }
 
@@ -402,23 +422,17 @@ static size_t scene_lds_bytes(const SceneView& sc) {
     return (small ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
 }
 
-template <bool FIRST, bool SMALL, bool MIS>
-static void launch_bounce_t(const BounceArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
-    hipLaunchKernelGGL((k_bounce<FIRST, SMALL, MIS>), dim3(grid), dim3(kBlock), lds_bytes, st, a);
-}
-
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
-void PT_LAUNCH(launch_bounce)(const BounceArgs& a, bool first, uint32_t grid, hipStream_t st) {
+void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
     const bool small = a.sc.n_objs <= kSmallObjs;
     const bool mis = a.integrator == 0;
     const size_t lds = scene_lds_bytes(a.sc);
-#define PT_CASE(F, S, M) \
-    if (first == F && small == S && mis == M) { launch_bounce_t<F, S, M>(a, grid, lds, st); return; }
-    PT_CASE(true, true, true) PT_CASE(true, true, false) PT_CASE(true, false, true) PT_CASE(true, false, false)
-    PT_CASE(false, true, true) PT_CASE(false, true, false) PT_CASE(false, false, true) PT_CASE(false, false, false)
-#undef PT_CASE
+    if (small && mis) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(kBlock), lds, st, a);
+    else if (small) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    else if (mis) hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(kBlock), lds, st, a);
 }
 }  // namespace ptk
 namespace PTK_IMPL {
