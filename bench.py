@@ -79,6 +79,21 @@ def cpu_baseline(pt, objs):
     }
 
 
+def pmc_traffic(world):
+    """HBM bytes per k_paths launch from the committed rocprofv3 PMC passes (profiles/r01/traffic.json:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command, tools/profile_gpu.sh).
+    PMC counters cannot be read from inside this process, so the figure is the last profiled one for this
+    exact workload (N = 1); null otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        return int(d["hbm_bytes_per_launch"]) if d.get("workload") == "C2 1024x1024x64" else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,13 +214,13 @@ def main():
                                                           f"one {args.backend} gather of the f32 + RGBA8 frame to rank 0",
             },
             "roofline": {
-                "kernel": "k_bounce (all bounce launches of rank 0)",
+                "kernel": "k_paths (one launch per sample batch: every bounce of every path), rank 0",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(world),
                 "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["launches"], 1)),
                 "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 4),
                 "launches": acc["launches"],

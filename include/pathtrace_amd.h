@@ -95,8 +95,8 @@ typedef struct {
      * (0 = library default).                                                  */
     uint64_t max_paths_in_flight;
     uint32_t profile;        /* 1: time every path-kernel launch with HIP events */
-    /* Workgroups (256 threads) of the persistent bounce grid; every wave owns one
-     * private queue segment.  0 = library default (4 per CU).  Results do not
+    /* Workgroups (256 threads) of the path kernel; every wave owns one private queue
+     * segment.  0 = library default (about 1024 paths per wave).  Results do not
      * depend on it.                                                           */
     uint32_t workgroups;
     /* Device arithmetic.  0 (default): hardware reciprocal / square root (1 ulp).  1: IEEE correctly
