@@ -74,6 +74,19 @@ PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& c
     id = obj;
 }
 
+// disc of SphereShape::hit only (the part every sphere pays), see sphere_test
+PT_DEV float sphere_disc(float4 s, f3 o, f3 d, float a, float inv_a) {
+    f3 oc = o - mk(s.x, s.y, s.z);
+    float k = dot(oc, d) * inv_a;
+    f3 l = madd(d, -k, oc);
+    return a * (s.w - dot(l, l));
+}
+
+// GROUPED (large scenes, where a given sphere is rarely hit): four discriminants, ONE wave-uniform
+// branch "did any lane hit any of the four?" instead of a divergent branch per sphere; the exact
+// sequential tests run only then.  max() drops NaNs unless all four are NaN, which is exactly the
+// NaN-ray case the reference lets through (Q10), so a NaN still reaches sphere_test.
+template <bool GROUPED>
 PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float a,
                      float inv_a, float t_min, float& closest, int& id) {
     if (tag == SHAPE_SPHERE) {
@@ -81,6 +94,11 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
         uint32_t i = 0;
         for (; i + 4u <= n; i += 4u) {
             float4 s0 = p[i], s1 = p[i + 1], s2 = p[i + 2], s3 = p[i + 3];
+            if (GROUPED) {
+                float m = __builtin_fmaxf(__builtin_fmaxf(sphere_disc(s0, o, d, a, inv_a), sphere_disc(s1, o, d, a, inv_a)),
+                                          __builtin_fmaxf(sphere_disc(s2, o, d, a, inv_a), sphere_disc(s3, o, d, a, inv_a)));
+                if (__ballot(!(m < 0.0f)) == 0ull) continue;
+            }
             sphere_test(s0, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
             sphere_test(s1, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 1);
             sphere_test(s2, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 2);
@@ -142,7 +160,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
         Run run = sc.runs[r];
         const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
         if (SMALL) {
-            scan_run(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
+            scan_run<false>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
         } else {
             float4* tile = const_cast<float4*>(sc.scan);
             const uint32_t tile_prims = kTileF4 / per;
@@ -152,13 +170,21 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
                 const float4* src = sc.scan_global + run.off4 + p0 * per;
                 for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) tile[k] = src[k];
                 __syncthreads();
-                scan_run(tile, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
+                scan_run<true>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
             }
         }
     }
     id_out = id;
     t_out = closest;
 }
+
+// Ray given to lanes that carry no path (or need no shadow ray).  It must FAIL every sphere
+// discriminant with a finite negative number: a zero ray gives a = 0, 1/a = inf, disc = NaN, and a
+// NaN falls through to the hit branch (reference semantics, Q10) -- one dead lane then drags its
+// whole wave through the sqrt/root logic of every sphere (measured on C4: 0.6 transcendental
+// instructions per sphere test).  From 3e18 along +x every |oc - (oc.d)d|^2 is ~1.8e37.
+PT_DEV f3 parked_origin() { return mk(3e18f, 3e18f, 3e18f); }
+PT_DEV f3 parked_dir() { return mk(1.0f, 0.0f, 0.0f); }
 
 // tile row -> image row (TileMap)
 PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
@@ -234,7 +260,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
 
     for (uint32_t it = 0; it < n_iter; ++it) {
         bool active;
-        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f), beta = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
+        f3 o = parked_origin(), d = parked_dir(), beta = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
         float pdf_prev = 0.0f, eta_in = 1.0f;
         uint32_t s_local = 0, depth = 0, px = 0, yl = 0, py = 0;
 
@@ -256,7 +282,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
             const uint32_t xy = __float_as_uint(n3.z), sd = __float_as_uint(n3.w);
             yl = xy >> 16; px = xy & 0xFFFFu;
             s_local = sd >> 16; depth = sd & 0xFFFFu;
-            if (!active) { o = mk(0.f, 0.f, 0.f); d = o; }
+            if (!active) { o = parked_origin(); d = parked_dir(); }
             // request the next chunk now; it is consumed just before this iteration's stores
             const uint32_t nxt = (it + 1u) * 64u + lane;
             if (nxt < n_in) {
@@ -338,8 +364,8 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
             if (any_shadow) {
                 // Ray::new (rendering.rs:62) would normalise light_dir a second time; the f32
                 // arithmetic specification normalises a direction once
-                f3 sdir = need_shadow ? light_dir : mk(0.f, 0.f, 0.f);
-                f3 sorg = need_shadow ? hit.point : mk(0.f, 0.f, 0.f);
+                f3 sdir = need_shadow ? light_dir : parked_dir();
+                f3 sorg = need_shadow ? hit.point : parked_origin();
                 int sid; float st;
                 scan_closest<SMALL>(sc, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
                 visible = need_shadow && sid < 0;
@@ -486,7 +512,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < n;
-        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
+        f3 o = parked_origin(), d = parked_dir();
         if (active) {
             o = mk(rays6[6 * (size_t)i], rays6[6 * (size_t)i + 1], rays6[6 * (size_t)i + 2]);
             d = normalize(mk(rays6[6 * (size_t)i + 3], rays6[6 * (size_t)i + 4], rays6[6 * (size_t)i + 5]));
