@@ -1,0 +1,70 @@
+"""Randomised scenes through the C ABI: spheres and triangles in arbitrary object order (so the LDS
+scan sees many runs), all four materials, several lights, random cameras, integrators and roulette
+policies.  exact_math = 1 must equal the f32 oracle bit for bit (NaNs included); the default mode
+must stay within the FP32 tolerance of it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F32, ITER = 32, 1
+
+
+def random_scene(pt, rng, n_objs):
+    specs = []
+    for i in range(n_objs):
+        kind = rng.integers(0, 2)
+        if kind == 0:
+            c = rng.uniform([-1, -1, -3], [1, 1, -1])
+            shape = (0, list(c) + [float(rng.uniform(0.05, 0.5))])
+        else:
+            v0 = rng.uniform([-1.2, -1.2, -3.2], [1.2, 1.2, -0.8])
+            shape = (1, list(v0) + list(v0 + rng.uniform(-1, 1, 3)) + list(v0 + rng.uniform(-1, 1, 3)))
+        m = rng.integers(0, 10)
+        if i < 2 or m == 0:
+            mat = (1, list(rng.uniform(2, 20, 3)))                       # emissive (at least two lights)
+        elif m <= 5:
+            mat = (0, list(rng.uniform(0.1, 0.9, 3)))                    # lambert
+        elif m <= 7:
+            mat = (2, [float(rng.uniform(0.05, 0.6))] + list(rng.uniform(0.5, 1, 3)) +
+                   [float(rng.choice([0.0, 1.0])), float(rng.uniform(1.1, 1.8))])   # GGX glass / metal
+        elif m == 8:
+            mat = (3, list(rng.uniform(0.2, 0.9, 3)) + [float(rng.uniform(0, 1))])  # oren-nayar
+        else:
+            mat = (1, [0.0, 0.0, 0.0])                                   # black "emissive": not a light (Q9)
+        specs.append((shape[0], shape[1], mat[0], mat[1]))
+    # a big enclosing diffuse sphere so that paths keep bouncing
+    specs.append((0, [0.0, 0.0, -2.0, 6.0], 0, [0.7, 0.7, 0.7]))
+    return pt.make_objects(specs)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_matches_f32_oracle(pt, orc, gpu_ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 40)) if seed < 6 else int(rng.integers(150, 400))   # the last two exceed one LDS blob
+    objs = random_scene(pt, rng, n)
+    has_oren = any(o.mat_tag == 3 for o in objs)
+    w, h = int(rng.integers(8, 48)), int(rng.integers(8, 48))
+    if rng.uniform() < 0.5:
+        cam = pt.camera_new(width=w, height=h, fov_degrees=float(rng.uniform(25, 60)))
+    else:
+        cam = pt.camera_look_at(tuple(rng.uniform([-0.8, -0.8, 0.5], [0.8, 0.8, 2.5])), (0.0, 0.0, -2.0), (0.0, 1.0, 0.0),
+                                w, h, float(rng.uniform(25, 60)))
+    prm = pt.default_params(spp=int(rng.integers(1, 6)), integrator=int(rng.integers(0, 2)),
+                            min_depth=int(rng.integers(0, 6)), max_depth=int(rng.integers(6, 30)), exact_math=1)
+    gpu_ctx.upload(objs)
+    lin, rgba = gpu_ctx.render(cam, prm)
+    st = gpu_ctx.stats()
+    ref, ref8, cnt = orc.render(cam, objs, prm, F32, ITER, 8)
+    got = lin.cpu().numpy()
+    if not has_oren:          # OrenNayar goes through libdevice atan2f/cosf: tolerance only
+        assert np.array_equal(got, ref.astype(np.float32), equal_nan=True), \
+            f"seed {seed}: {(got != ref.astype(np.float32)).any(-1).sum()} pixels differ"
+        assert np.array_equal(rgba.cpu().numpy(), ref8)
+        assert st.vertices == cnt["vertices"] and st.shadow_rays == cnt["shadow_rays"]
+    fin = np.isfinite(ref).all(-1)
+    prm.exact_math = 0
+    fast, _ = gpu_ctx.render(cam, prm)
+    for img in ([got, fast.cpu().numpy()] if has_oren else [fast.cpu().numpy()]):
+        g = img.astype(np.float64)
+        ok = (np.abs(g - ref) <= 1e-3 + 1e-2 * np.abs(ref)).all(-1)
+        assert ok[fin].mean() >= 0.97, (seed, ok[fin].mean())
