@@ -3,6 +3,7 @@
 // World.data instead of blitting it to a winit/pixels surface (out of scope).
 //
 //   ./cornell [width height spp [out_prefix [exact_math]]]        defaults: 400 400 64 cornell 0
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +49,13 @@ int main(int argc, char** argv) {
         world.params().spp = spp;
         world.params().exact_math = exact_math;
         const auto t0 = std::chrono::steady_clock::now();
-        world.render();
+        if (std::getenv("CORNELL_PROGRESSIVE"))      // live-preview form: one line per increment
+            world.render_progressive(std::max(1u, spp / 4), [&](uint32_t done) {
+                std::printf("  preview after %u spp: centre pixel rgb = %u %u %u\n", done, world.data[(h / 2) * w + w / 2].r,
+                            world.data[(h / 2) * w + w / 2].g, world.data[(h / 2) * w + w / 2].b);
+                return false; });
+        else
+            world.render();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const PtStats st = world.stats();
         std::printf("Rendering complete: %ux%u, %u spp, %zu objects, %.3f s (%.1f Msamples/s), %llu vertices\n", w, h, spp,

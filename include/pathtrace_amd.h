@@ -173,6 +173,16 @@ int pt_get_stats(PtContext* ctx, PtStats* out);
 int pt_render_host(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
                    float* out_linear_rgb, uint8_t* out_rgba8);
 
+/* Progressive preview (the reference redraws World.data every 16 ms while the rayon loop fills it,
+ * src/main.rs:79-90): the same render in increments of spp_step samples.  After each increment the
+ * host buffers hold the mean of the samples so far and fn is called; a non-zero return stops early.
+ * The final frame is bit-identical to pt_render_host with the same parameters.                    */
+typedef int (*PtProgressFn)(void* user, uint32_t spp_done, uint32_t spp_total,
+                            const uint8_t* rgba8, const float* linear_rgb);
+int pt_render_progressive(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
+                          uint32_t spp_step, PtProgressFn fn, void* user,
+                          float* out_linear_rgb, uint8_t* out_rgba8);
+
 /* One-shot convenience with HOST buffers: create context on device 0 (cached),
  * upload, render, copy back.  = everything src/main.rs:43-60 does.            */
 int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n_objs,

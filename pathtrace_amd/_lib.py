@@ -86,12 +86,16 @@ SYMBOLS = {
     "pt_sync": (C.c_int, [C.c_void_p]),
     "pt_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
     "pt_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_render_progressive": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double, C.c_uint32,
                                      _P(C.c_int32), _P(C.c_float)]),
     "pt_last_error": (C.c_char_p, []),
     "pt_abi_version": (C.c_uint32, []),
 }
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_float))
 
 _lib = None
 

@@ -126,6 +126,20 @@ class Context:
         self.sync()
         return lin, rgba
 
+    def render_progressive(self, cam, params, spp_step, on_frame=None):
+        """pt_render_progressive: on_frame(spp_done, spp_total, rgba[rows,W,4], linear[rows,W,3]) -> truthy to stop."""
+        rows = tile_rows(cam.height, params.band_rows, params.band_index, params.band_count or 1)
+        lin = np.zeros((rows, cam.width, 3), dtype=np.float32)
+        rgba = np.zeros((rows, cam.width, 4), dtype=np.uint8)
+
+        def _cb(user, done, total, p8, pf):
+            return int(bool(on_frame(done, total, rgba.copy(), lin.copy()))) if on_frame else 0
+
+        cb = _lib.PROGRESS_FN(_cb)
+        check(lib().pt_render_progressive(self._h, C.byref(cam), C.byref(params), spp_step, C.cast(cb, C.c_void_p), None,
+                                          lin.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p)))
+        return lin, rgba
+
     def debug_hit_scene(self, rays, t_min=0.001, t_max=float("inf"), exact_math=0):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = rays.shape[0]

@@ -86,6 +86,9 @@ struct PtContext {
     PtStats stats{};
     bool stats_pending = false;
     uint32_t profiled_batches = 0;
+    // progressive rendering (pt_render_progressive): carry the f64 film sums across calls
+    bool prog_load = false, prog_store = false;
+    uint32_t prog_div = 0;
 };
 
 namespace {
@@ -326,7 +329,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         if ((rc = c->queue[k].ensure(q_slots))) return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if ((rc = c->dstats.ensure(8))) return rc;
-    if (n_batches > 1 && (rc = c->film.ensure((size_t)np * 3))) return rc;
+    if ((n_batches > 1 || c->prog_load || c->prog_store) && (rc = c->film.ensure((size_t)np * 3))) return rc;
 
     ptk::BounceArgs a{};
     for (int k = 0; k < 4; ++k) a.q.q[k] = c->queue[k].p;
@@ -373,9 +376,10 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         r.out_linear = d_linear;
         r.out_rgba = d_rgba;
         r.np = np; r.nb = nb;
-        r.first_batch = batch == 0;
-        r.last_batch = batch + 1 == n_batches;
-        r.spp_total = prm->spp;
+        r.load_film = batch > 0 || c->prog_load;
+        r.store_film = batch + 1 < n_batches || c->prog_store;
+        r.finalize = batch + 1 == n_batches;
+        r.spp_div = c->prog_div ? c->prog_div : prm->spp;
         ptk::launch_resolve(r, st);
         HIP_TRY(hipGetLastError());
     }
@@ -454,6 +458,35 @@ int pt_render_host(PtContext* c, const PtCamera* cam, const PtRenderParams* prm,
     HIP_TRY(hipMemcpy(out_linear, c->host_lin.p, np * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, c->host_rgba.p, np * 4, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+// The progressive preview of the reference (main.rs:79-90 redraws World.data every 16 ms while
+// the rayon loop fills it): the same render in increments of spp_step samples; after each increment
+// the film holds the mean of the samples so far.  The last frame is bit-identical to pt_render_host.
+int pt_render_progressive(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, uint32_t spp_step,
+                          PtProgressFn fn, void* user, float* out_linear, uint8_t* out_rgba) {
+    if (!c || !cam || !prm || !out_linear || !out_rgba)
+        return fail(PT_ERR_INVALID_ARG, "pt_render_progressive: null argument");
+    if (prm->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
+    if (spp_step == 0) spp_step = prm->spp;
+    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
+    const size_t np = (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
+    int rc = PT_OK;
+    for (uint32_t done = 0; done < prm->spp && rc == PT_OK;) {
+        const uint32_t n = std::min(spp_step, prm->spp - done);
+        PtRenderParams p = *prm;
+        p.spp = n;
+        p.spp_offset = prm->spp_offset + done;
+        c->prog_load = done > 0;
+        c->prog_store = done + n < prm->spp;
+        c->prog_div = done + n;
+        rc = pt_render_host(c, cam, &p, out_linear, out_rgba);
+        c->prog_load = c->prog_store = false;
+        c->prog_div = 0;
+        done += n;
+        if (rc == PT_OK && np != 0 && fn && fn(user, done, prm->spp, out_rgba, out_linear) != 0) break;   // caller asked to stop
+    }
+    return rc;
 }
 
 int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRenderParams* prm, float* out_linear,

@@ -81,7 +81,7 @@ void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);
 void launch_paths_fast(const BounceArgs& a, uint32_t grid, hipStream_t st);
 
 // Film: sum the nb samples of every tile pixel in sample order into the f64
-// accumulator (world.rs:311), and on the last batch write mean, sqrt-gamma and
+// accumulator (world.rs:311), and when finalising write mean, sqrt-gamma and
 // truncated RGBA8 (world.rs:315-332).
 struct ResolveArgs {
     const float4* lsamp;
@@ -89,8 +89,10 @@ struct ResolveArgs {
     float* out_linear;        // np*3
     uint8_t* out_rgba;        // np*4 or null
     uint32_t np, nb;
-    uint32_t first_batch, last_batch;
-    uint32_t spp_total;
+    uint32_t load_film;       // start from the f64 sums in `film` (not the first samples of the pixel)
+    uint32_t store_film;      // keep the sums in `film` (more samples follow)
+    uint32_t finalize;        // write the outputs: mean over spp_div samples, gamma, quantisation
+    uint32_t spp_div;
 };
 void launch_resolve(const ResolveArgs& a, hipStream_t st);
 

@@ -471,16 +471,14 @@ __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= a.np) return;
     double r = 0.0, g = 0.0, b = 0.0;
-    if (!a.first_batch) { r = a.film[3 * (size_t)p]; g = a.film[3 * (size_t)p + 1]; b = a.film[3 * (size_t)p + 2]; }
+    if (a.load_film) { r = a.film[3 * (size_t)p]; g = a.film[3 * (size_t)p + 1]; b = a.film[3 * (size_t)p + 2]; }
     for (uint32_t s = 0; s < a.nb; ++s) {
         float4 v = a.lsamp[(size_t)s * a.np + p];
         r += (double)v.x; g += (double)v.y; b += (double)v.z;                     // world.rs:311
     }
-    if (!a.last_batch) {
-        a.film[3 * (size_t)p] = r; a.film[3 * (size_t)p + 1] = g; a.film[3 * (size_t)p + 2] = b;
-        return;
-    }
-    double c[3] = {r / (double)a.spp_total, g / (double)a.spp_total, b / (double)a.spp_total};   // world.rs:315
+    if (a.store_film) { a.film[3 * (size_t)p] = r; a.film[3 * (size_t)p + 1] = g; a.film[3 * (size_t)p + 2] = b; }
+    if (!a.finalize) return;
+    double c[3] = {r / (double)a.spp_div, g / (double)a.spp_div, b / (double)a.spp_div};   // world.rs:315
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         a.out_linear[3 * (size_t)p + k] = (float)c[k];                            // luminance_data, world.rs:318-319

@@ -171,6 +171,27 @@ public:
         p.band_rows = 0; p.band_index = 0; p.band_count = 1;
         render_host(p);
     }
+    // Progressive form of render(): after every spp_step samples `data` / `luminance_data` hold the mean so
+    // far and on_frame(spp_done) is called -- what the reference's window shows while rendering
+    // (main.rs:79-90).  on_frame returning true stops early.  The last frame equals render()'s.
+    template <class F> void render_progressive(uint32_t spp_step, F on_frame, int device = 0) {
+        if (!ctx_) check(pt_context_create(device, &ctx_));
+        check(pt_scene_upload(ctx_, objects_.data(), (uint32_t)objects_.size()));
+        resize_film();
+        PtRenderParams p = params_;
+        p.band_rows = 0; p.band_index = 0; p.band_count = 1;
+        const size_t n = (size_t)camera_.width() * camera_.height();
+        std::vector<float> lin(n * 3);
+        std::vector<uint8_t> rgba(n * 4);
+        struct Ctx { World* w; F* f; std::vector<float>* lin; std::vector<uint8_t>* rgba; } cx{this, &on_frame, &lin, &rgba};
+        auto tramp = [](void* u, uint32_t done, uint32_t, const uint8_t*, const float*) -> int {
+            Ctx* c = static_cast<Ctx*>(u);
+            c->w->unpack(*c->lin, *c->rgba);
+            return (*c->f)(done) ? 1 : 0;
+        };
+        check(pt_render_progressive(ctx_, &camera_.pod(), &p, spp_step, tramp, &cx, lin.data(), rgba.data()));
+        unpack(lin, rgba);
+    }
     PtStats stats() { PtStats s{}; if (ctx_) check(pt_get_stats(ctx_, &s)); return s; }
 
     // World::draw (world.rs:335-341): blit RGBA8 into a frame of 4*W*H bytes
@@ -219,7 +240,10 @@ private:
         std::vector<float> lin(n * 3);
         std::vector<uint8_t> rgba(n * 4);
         check(pt_render_host(ctx_, &camera_.pod(), &p, lin.data(), rgba.data()));
-        for (size_t i = 0; i < n; ++i) {
+        unpack(lin, rgba);
+    }
+    void unpack(const std::vector<float>& lin, const std::vector<uint8_t>& rgba) {
+        for (size_t i = 0; i < data.size(); ++i) {
             luminance_data[i] = Vector3(lin[3 * i], lin[3 * i + 1], lin[3 * i + 2]);
             data[i] = Color{rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]};
         }

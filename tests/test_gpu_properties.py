@@ -115,3 +115,21 @@ def test_edge_sizes(pt, orc, gpu_ctx):
     cam = pt.camera_new(width=8, height=8)
     lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=2, band_rows=64, band_index=1, band_count=2))
     assert lin.shape[0] == 0 and gpu_ctx.stats().samples == 0
+
+
+def test_progressive_preview_ends_bit_identical_to_one_shot(pt, gpu_ctx):
+    """pt_render_progressive (the reference's live window, main.rs:79-90): frames after k samples equal a
+    one-shot render of k samples, the last frame equals the full render, and the callback can stop early."""
+    gpu_ctx.upload(pt.builtin_scene(1))
+    cam = pt.camera_new(width=96, height=64)
+    frames = []
+    lin, rgba = gpu_ctx.render_progressive(cam, pt.default_params(spp=10), 4,
+                                           lambda done, total, f8, fl: frames.append((done, total, f8, fl)) and False)
+    assert [f[0] for f in frames] == [4, 8, 10] and all(f[1] == 10 for f in frames)
+    for done, _, f8, fl in frames:
+        one, one8, _ = _render(pt, gpu_ctx, cam, spp=done)
+        assert np.array_equal(fl, one) and np.array_equal(f8, one8)
+    assert np.array_equal(lin, frames[-1][3]) and np.array_equal(rgba, frames[-1][2])
+    seen = []
+    gpu_ctx.render_progressive(cam, pt.default_params(spp=10), 3, lambda done, *_: seen.append(done) or done >= 6)
+    assert seen == [3, 6]
