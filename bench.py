@@ -35,6 +35,15 @@ if ROOT not in sys.path:
 
 WIDTH = HEIGHT = 1024
 SPP = 64
+# --workload: the other BASELINE.json configs through the same harness (default c2 = the headline config).
+# name -> (scene id, scene arg, width, height, spp, description)
+WORKLOADS = {
+    "c1": (1, 0, 1024, 1024, 64, "C1: reference Cornell box + GGX glass sphere (World::new(), 13 objects)"),
+    "c2": (2, 0, 1024, 1024, 64, "C2: 10-sphere diffuse Cornell scene"),
+    "c3": (2, 0, 1024, 1024, 4096, "C3: 10-sphere diffuse Cornell scene, steady state"),
+    "c4": (4, 10000, 1024, 1024, 256, "C4: 10 000 random spheres (100 lights), brute-force LDS-tiled scan"),
+    "c5": (2, 0, 3840, 2160, 1024, "C5: 10-sphere diffuse Cornell scene, 4K"),
+}
 BYTES_PER_VERTEX = 252      # extend 32 + shade 144 + shadow/accumulate 68 + compaction 8
 BYTES_PER_SAMPLE = 64       # ray generation 52 + final radiance 12
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
@@ -79,13 +88,13 @@ def cpu_baseline(pt, objs):
     }
 
 
-def pmc_traffic(world):
+def pmc_traffic(world, workload="c2"):
     """HBM bytes per k_paths launch from the committed rocprofv3 PMC passes (profiles/r01/traffic.json:
     FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command, tools/profile_gpu.sh).
     PMC counters cannot be read from inside this process, so the figure is the last profiled one for this
     exact workload (N = 1); null otherwise."""
     path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    if world != 1 or not os.path.exists(path):
+    if world != 1 or workload != "c2" or not os.path.exists(path):
         return None
     try:
         d = json.load(open(path))
@@ -102,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0, help="PtRenderParams.max_paths_in_flight (0 = default)")
     ap.add_argument("--workgroups", type=int, default=0)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
                          "goes through host memory); the driver's runs use nccl (RCCL)")
@@ -130,7 +140,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    objs = pt.builtin_scene(2)
+    global WIDTH, HEIGHT, SPP
+    scene_id, scene_arg, WIDTH, HEIGHT, SPP, wl_desc = WORKLOADS[args.workload]
+    if args.workload != "c2":
+        args.no_cpu_baseline = True          # the CPU baseline leg is defined on the headline config
+    objs = pt.builtin_scene(scene_id, scene_arg)
     cam = pt.camera_new(width=WIDTH, height=HEIGHT)
     spp = SPP * world
     band_rows = default_band_rows(HEIGHT, world) if world > 1 else 0
@@ -193,7 +207,8 @@ def main():
         alg_bytes = BYTES_PER_VERTEX * acc["vertices"] + BYTES_PER_SAMPLE * acc["samples"]
         achieved = alg_bytes / (acc["bounce_ms"] * 1e-3) / 1e9 if acc["bounce_ms"] > 0 else 0.0
         out = {
-            "metric": "Msamples/sec (pixels x spp / s) at 1024^2/64spp",
+            "metric": "Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2"
+                      else f"Msamples/sec (pixels x spp / s) at {WIDTH}x{HEIGHT}/{SPP}spp",
             "value": round(job_samples / elapsed / 1e6, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -206,7 +221,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: 10-sphere diffuse Cornell scene, {WIDTH}x{HEIGHT}, {spp} spp "
+                "workload": f"{wl_desc}, {WIDTH}x{HEIGHT}, {spp} spp "
                             f"({SPP} spp per GPU), MIS, min_depth 4 / max_depth 50",
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
@@ -220,7 +235,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(world),
+                "traffic": pmc_traffic(world, args.workload),
                 "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["launches"], 1)),
                 "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 4),
                 "launches": acc["launches"],
