@@ -1,4 +1,4 @@
-"""Committed fixtures (tests/golden, written by tools/make_golden.py from the f64
+"""Committed fixtures (tests/golden, written by tests/tools/make_golden.py from the f64
 recursive oracle).  CPU: the oracle still reproduces them.  GPU (-m gpu): the HIP
 path matches them within the FP32 tolerance.  Image fixtures use the reference's
 own luminance.csv format (src/world.rs:344-369, 6 decimals)."""

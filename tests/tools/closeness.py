@@ -1,6 +1,6 @@
 """How close is a library build to the f32 oracle?  PATHTRACE_AMD_LIB selects the build."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import pathtrace_amd as pt
 from oracle import orc

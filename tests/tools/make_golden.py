@@ -3,10 +3,10 @@ restatement, oracle/pt_oracle.hpp).  The reference tree holds no golden vector f
 this path, so these fixtures pin the oracle against drift and give the
 GPU tests a committed f64 target; they are data only (inputs + expected outputs).
 
-    python tools/make_golden.py          # rewrites tests/golden/
+    python tests/tools/make_golden.py          # rewrites tests/golden/
 """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import pathtrace_amd as pt
