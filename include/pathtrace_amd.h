@@ -145,7 +145,11 @@ int pt_builtin_scene(uint32_t id, uint32_t arg, PtObject* objs, uint32_t cap, ui
 
 typedef struct PtContext PtContext;
 
-/* One context per process per GPU.  device = HIP device ordinal. */
+/* One context per process per GPU.  device = HIP device ordinal.
+ * Threading: a context is NOT internally synchronised -- use it from one thread at a time (the
+ * reference calls render_pixel from every rayon worker; this library is called once from the render
+ * thread and parallelises on the GPU).  Different contexts may be used from different threads.
+ * pt_last_error() is thread-local.  pt_render() serialises its callers on one cached context.   */
 int pt_context_create(int device, PtContext** out);
 int pt_context_destroy(PtContext* ctx);
 /* Run the library's kernels on a caller-owned hipStream_t (e.g. torch's current

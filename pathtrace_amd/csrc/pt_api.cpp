@@ -428,18 +428,18 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
     HIP_TRY(hipSetDevice(c->device));
     std::vector<float> r6(6 * (size_t)n);
     for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];
-    float* d_r = nullptr; int32_t* d_id = nullptr; float* d_t = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_r, r6.size() * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&d_id, n * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&d_t, n * sizeof(float)));
-    HIP_TRY(hipMemcpy(d_r, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (exact_math) ptk::launch_debug_hit_exact(c->view, d_r, n, (float)t_min, (float)t_max, d_id, d_t, c->stream);
-    else ptk::launch_debug_hit_fast(c->view, d_r, n, (float)t_min, (float)t_max, d_id, d_t, c->stream);
+    DevBuf<float> d_r, d_t;
+    DevBuf<int32_t> d_id;
+    struct Release { DevBuf<float>&a, &b; DevBuf<int32_t>& c; ~Release() { a.release(); b.release(); c.release(); } } guard{d_r, d_t, d_id};
+    int rc;
+    if ((rc = d_r.ensure(r6.size())) || (rc = d_id.ensure(n)) || (rc = d_t.ensure(n))) return rc;
+    HIP_TRY(hipMemcpy(d_r.p, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (exact_math) ptk::launch_debug_hit_exact(c->view, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
+    else ptk::launch_debug_hit_fast(c->view, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out_id, d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_t, d_t, n * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(d_r); (void)hipFree(d_id); (void)hipFree(d_t);
+    HIP_TRY(hipMemcpy(out_id, d_id.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

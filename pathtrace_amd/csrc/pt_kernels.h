@@ -72,7 +72,7 @@ constexpr uint32_t kBlock = 256;
 // records: at most 9 float4 per object = 18 KiB); larger scenes stream their scan array
 // through one LDS tile and gather shape/material records from global memory.
 constexpr uint32_t kSmallObjs = 128;
-constexpr uint32_t kTileF4 = 3072;         // 48 KiB LDS tile (divisible by 3: whole triangles)
+constexpr uint32_t kTileF4 = 2550;         // 39.8 KiB LDS tile (divisible by 3: whole triangles); 4 workgroups per CU
 
 // One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
 // (4 queue segments each).  _exact / _fast: the two arithmetic modes of pt_device.h

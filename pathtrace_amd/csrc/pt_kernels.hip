@@ -228,7 +228,12 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (kBlock / 64);
-    const uint32_t seg_base = wave * a.seg_cap;
+    // SMALL: one private segment per wave.  Tiled: the four waves of a workgroup advance in lockstep anyway
+    // (barriers in the scan), so they share ONE segment and compact at workgroup level: chunk c of a pass
+    // goes to wave c % 4 and only the last chunk of a pass is partial (every pass costs a full scan of the
+    // whole scene per wave, however few lanes are alive).
+    const uint32_t wib = threadIdx.x >> 6;                       // wave in block
+    const uint32_t seg_base = SMALL ? wave * a.seg_cap : blockIdx.x * (kBlock / 64) * a.seg_cap;
     const uint32_t n_chunks = (a.n_first + 63u) >> 6;              // pass 0: 64-path chunks of the batch
     const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
     const uint32_t W = a.cam.width;
@@ -237,24 +242,18 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
 
     for (uint32_t pass = 0;; ++pass) {
     const bool first = pass == 0u;
-    uint32_t n_iter = first ? (n_chunks + nw - 1u) / nw : (n_in + 63u) >> 6;
-    if (!SMALL) {
-        // the tiled scan synchronises the workgroup: every wave runs the longest wave's trip count
-        __syncthreads();
-        if (lane == 0u) s_iters[threadIdx.x >> 6] = n_iter;
-        __syncthreads();
-        uint32_t m = 0;
-        for (uint32_t k = 0; k < kBlock / 64; ++k) m = s_iters[k] > m ? s_iters[k] : m;
-        n_iter = m;
-    }
-    if (n_iter == 0u) break;               // SMALL: this wave is done; tiled: the whole workgroup is
+    // SMALL: n_in = paths of this wave's segment; tiled: n_in = paths of the workgroup's segment (same in all waves)
+    const uint32_t n_iter = first ? (n_chunks + nw - 1u) / nw : (SMALL ? (n_in + 63u) >> 6 : (n_in + kBlock - 1u) / kBlock);
+    if (n_iter == 0u) break;               // SMALL: this wave is done; tiled: the whole workgroup is (uniform)
     if (n_in != 0u || first) wave_depth = pass;
     uint32_t out_n = 0;                    // wave-uniform: survivors written so far in this pass
 
     // state of the next chunk, in flight
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
-    if (!first && lane < n_in) {
-        const uint32_t s0 = seg_base + lane;
+    const uint32_t lane_off = SMALL ? lane : wib * 64u + lane;   // position inside a chunk (64 or 256 slots)
+    const uint32_t chunk_slots = SMALL ? 64u : kBlock;
+    if (!first && lane_off < n_in) {
+        const uint32_t s0 = seg_base + lane_off;
         n0 = a.q.q[0][s0]; n1 = a.q.q[1][s0]; n2 = a.q.q[2][s0]; n3 = a.q.q[3][s0];
     }
 
@@ -275,7 +274,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
                 px = pix - yl * W;
             }
         } else {
-            active = it * 64u + lane < n_in;
+            active = it * chunk_slots + lane_off < n_in;
             o = mk(n0.x, n0.y, n0.z); d = mk(n0.w, n1.x, n1.y);
             beta = mk(n1.z, n1.w, n2.x); L = mk(n2.y, n2.z, n2.w);
             pdf_prev = n3.x; eta_in = n3.y;
@@ -284,7 +283,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
             s_local = sd >> 16; depth = sd & 0xFFFFu;
             if (!active) { o = parked_origin(); d = parked_dir(); }
             // request the next chunk now; it is consumed just before this iteration's stores
-            const uint32_t nxt = (it + 1u) * 64u + lane;
+            const uint32_t nxt = (it + 1u) * chunk_slots + lane_off;
             if (nxt < n_in) {
                 const uint32_t s1 = seg_base + nxt;
                 n0 = a.q.q[0][s1]; n1 = a.q.q[1][s1]; n2 = a.q.q[2][s1]; n3 = a.q.q[3][s1];
@@ -420,19 +419,29 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
         // ---- retire, or compact in place into the wave's own segment
         if (active && !alive) a.lsamp[s_local * a.np + yl * W + px] = make_float4(L.x, L.y, L.z, 0.0f);
         const unsigned long long mask = __ballot(alive);
+        uint32_t cnt_before = 0, cnt_all = (uint32_t)__popcll(mask);
+        if (!SMALL) {
+            // workgroup-level prefix of the survivor counts (s_iters is free: the next write to it is an
+            // iteration away, behind the barriers of two scans)
+            if (lane == 0u) s_iters[wib] = cnt_all;
+            __syncthreads();
+            cnt_all = 0;
+            for (uint32_t k = 0; k < kBlock / 64; ++k) { cnt_before += k < wib ? s_iters[k] : 0u; cnt_all += s_iters[k]; }
+        }
         if (alive) {
-            const uint32_t j = seg_base + out_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint32_t j = seg_base + out_n + cnt_before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             a.q.q[0][j] = make_float4(o.x, o.y, o.z, d.x);
             a.q.q[1][j] = make_float4(d.y, d.z, beta.x, beta.y);
             a.q.q[2][j] = make_float4(beta.z, L.x, L.y, L.z);
             a.q.q[3][j] = make_float4(pdf_prev, eta_in, __uint_as_float((yl << 16) | px),
                                       __uint_as_float((s_local << 16) | depth));
         }
-        out_n += (uint32_t)__popcll(mask);
+        out_n += cnt_all;
     }
     n_in = out_n;
-    // the next pass reads (from other lanes of this wave) what this pass stored
+    // the next pass reads (from other lanes of this wave -- tiled: of this workgroup) what this pass stored
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (!SMALL) __syncthreads();
     if (SMALL && n_in == 0u) break;
     }   // pass loop
     if (lane == 0u) {
