@@ -53,9 +53,16 @@ struct TileMap {
 
 struct BounceArgs {
     Queue q;                  // compacted in place, one private segment per wave
+    // tail hand-off between launches (small scenes): a wave whose segment falls below export_below paths
+    // appends them to ovf_out (slot = atomicAdd(ovf_out_count, n)) and retires; a continuation launch
+    // (src_mode = 1) takes its n_first paths from ovf_in instead of generating camera rays
+    Queue ovf_in, ovf_out;
+    uint32_t* ovf_out_count;
+    uint32_t src_mode;        // 0: pass 0 generates camera rays, 1: pass 0 reads ovf_in
+    uint32_t export_below;    // >= 1; 1 = never export (a wave runs until its segment is empty)
     uint32_t seg_cap;         // slots per segment (multiple of 64)
     float4* lsamp;            // per-path final radiance, index = s_local*np + tile_row*width + x
-    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest pass (max)
+    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)
     TileMap tile;
     SceneView sc;
     CameraF cam;

@@ -220,7 +220,7 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4      // minimum waves per SIMD the register allocator must leave room for
 #endif
-template <bool SMALL, bool MIS>
+template <bool SMALL, bool MIS, bool OVF>   // OVF: continuation launch, pass 0 reads the overflow queue
 __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a) {
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
@@ -238,14 +238,15 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
     const uint32_t W = a.cam.width;
     uint32_t n_in = 0;                     // wave-uniform: queued paths of this wave's segment
-    uint32_t wave_shadow = 0, wave_vertices = 0, wave_depth = 0;
+    uint32_t wave_shadow = 0, wave_vertices = 0;
+    uint32_t wave_depth = 0;               // wave-uniform: deepest vertex this wave has processed
+    constexpr bool from_overflow = OVF;
 
     for (uint32_t pass = 0;; ++pass) {
     const bool first = pass == 0u;
     // SMALL: n_in = paths of this wave's segment; tiled: n_in = paths of the workgroup's segment (same in all waves)
     const uint32_t n_iter = first ? (n_chunks + nw - 1u) / nw : (SMALL ? (n_in + 63u) >> 6 : (n_in + kBlock - 1u) / kBlock);
     if (n_iter == 0u) break;               // SMALL: this wave is done; tiled: the whole workgroup is (uniform)
-    if (n_in != 0u || first) wave_depth = pass;
     uint32_t out_n = 0;                    // wave-uniform: survivors written so far in this pass
 
     // state of the next chunk, in flight
@@ -268,10 +269,22 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
             const uint32_t pid = chunk * 64u + lane;
             active = chunk < n_chunks && pid < a.n_first;
             if (active) {
-                s_local = pid / a.np;
-                const uint32_t pix = pid - s_local * a.np;
-                yl = pix / W;
-                px = pix - yl * W;
+                if (from_overflow) {
+                    // continuation launch: the paths are the leftovers an earlier launch exported
+                    const float4 q0 = a.ovf_in.q[0][pid], q1 = a.ovf_in.q[1][pid], q2 = a.ovf_in.q[2][pid],
+                                 q3 = a.ovf_in.q[3][pid];
+                    o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y);
+                    beta = mk(q1.z, q1.w, q2.x); L = mk(q2.y, q2.z, q2.w);
+                    pdf_prev = q3.x; eta_in = q3.y;
+                    const uint32_t xy = __float_as_uint(q3.z), sd = __float_as_uint(q3.w);
+                    yl = xy >> 16; px = xy & 0xFFFFu;
+                    s_local = sd >> 16; depth = sd & 0xFFFFu;
+                } else {
+                    s_local = pid / a.np;
+                    const uint32_t pix = pid - s_local * a.np;
+                    yl = pix / W;
+                    px = pix - yl * W;
+                }
             }
         } else {
             active = it * chunk_slots + lane_off < n_in;
@@ -292,7 +305,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
         py = image_row(a.tile, yl);                  // key of the path's RNG stream = (x, y), main.rs:51
         const uint32_t sample = a.s_base + s_local;
 
-        if (first && active) {
+        if (first && !from_overflow && active) {
             uint32_t dc[4];
             philox4x32_10(sample, kDepthCamera, 0u, 0u, px, py, dc);
             float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
@@ -306,6 +319,15 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
         }
 
         wave_vertices += (uint32_t)__popcll(__ballot(active));
+        // deepest vertex: in a level-0 launch every path of pass p is at depth p; only a continuation launch
+        // mixes depths inside a wave and has to look at the lanes
+        if (!from_overflow) {
+            wave_depth = pass;
+        } else if (__ballot(active && depth > wave_depth) != 0ull) {
+            uint32_t v = active ? depth : 0u;
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)v, off); v = w2 > v ? w2 : v; }
+            wave_depth = __builtin_amdgcn_readfirstlane(v);
+        }
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
@@ -442,13 +464,27 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     // the next pass reads (from other lanes of this wave -- tiled: of this workgroup) what this pass stored
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (!SMALL) __syncthreads();
-    if (SMALL && n_in == 0u) break;
+    if (SMALL && n_in < a.export_below) break;       // export_below >= 1: an empty segment always ends the wave
     }   // pass loop
+
+    // Tail hand-off.  Below one chunk a wave would run every further pass mostly empty (and one path trapped
+    // in a glass sphere keeps it alive for 50 passes).  Instead it appends what is left to the global
+    // overflow queue -- one atomic per wave per launch -- and retires; the host launches this kernel again
+    // on that queue (from_overflow), where the leftovers of ~65 000 waves form dense chunks again.
+    if (SMALL && n_in != 0u) {
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(a.ovf_out_count, n_in);
+        base = __shfl(base, 0);
+        if (lane < n_in) {
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + lane]; a.ovf_out.q[k][base + lane] = t; }
+        }
+    }
     if (lane == 0u) {
-        // totals for the host: shadow rays, vertices (= loop iterations summed over paths), deepest pass
+        // totals for the host: shadow rays, vertices (= loop iterations summed over paths), deepest vertex
         if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
-        atomicMax(&a.stats[2], (unsigned long long)wave_depth);
+        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
     }
 }
 
@@ -463,11 +499,15 @@ using namespace PTK_IMPL;
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
     const bool small = a.sc.n_objs <= kSmallObjs;
     const bool mis = a.integrator == 0;
+    const bool ovf = a.src_mode != 0u;     // continuation launches exist for small scenes only
     const size_t lds = scene_lds_bytes(a.sc);
-    if (small && mis) hipLaunchKernelGGL((k_paths<true, true>), dim3(grid), dim3(kBlock), lds, st, a);
-    else if (small) hipLaunchKernelGGL((k_paths<true, false>), dim3(grid), dim3(kBlock), lds, st, a);
-    else if (mis) hipLaunchKernelGGL((k_paths<false, true>), dim3(grid), dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((k_paths<false, false>), dim3(grid), dim3(kBlock), lds, st, a);
+    const dim3 g(grid), b(kBlock);
+    if (small && mis && !ovf) hipLaunchKernelGGL((k_paths<true, true, false>), g, b, lds, st, a);
+    else if (small && mis) hipLaunchKernelGGL((k_paths<true, true, true>), g, b, lds, st, a);
+    else if (small && !ovf) hipLaunchKernelGGL((k_paths<true, false, false>), g, b, lds, st, a);
+    else if (small) hipLaunchKernelGGL((k_paths<true, false, true>), g, b, lds, st, a);
+    else if (mis) hipLaunchKernelGGL((k_paths<false, true, false>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_paths<false, false, false>), g, b, lds, st, a);
 }
 }  // namespace ptk
 namespace PTK_IMPL {
