@@ -334,9 +334,10 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     if (grid == 0) grid = 1;
     const uint32_t nw = grid * kWavesPerBlock;
     const uint32_t seg_cap = ((chunks_max + nw - 1) / nw) * 64u;
-    const bool hand_off = c->view.n_objs <= ptk::kSmallObjs;        // the tiled variant compacts per workgroup instead
+    const bool hand_off = true;
+    const bool small_scene = c->view.n_objs <= ptk::kSmallObjs;     // tiled scenes export per workgroup (< 256 paths)
     const uint32_t nw_cont = std::max(nw, kMinGrid * kWavesPerBlock);    // waves of any continuation launch
-    const size_t ovf_slots = (size_t)nw_cont * 64u;                      // a wave exports < 64 paths
+    const size_t ovf_slots = (size_t)nw_cont * 64u;                      // a wave exports < 64 paths (a workgroup < 256)
     // level 0 needs nw*seg_cap slots; a continuation launch of n <= nw*63 paths needs <= n + 64 + nw_cont*64
     const size_t q_slots = std::max((size_t)nw * seg_cap, (size_t)nw * 63u + 64u + (size_t)nw_cont * 64u);
 
@@ -399,7 +400,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             a.n_first = n_level;
             a.seg_cap = ((chunks + nw_l - 1) / nw_l) * 64u;
             a.src_mode = level > 0 ? 1u : 0u;
-            a.export_below = (hand_off && n_level > kExportMinPaths) ? 64u : 1u;
+            a.export_below = (hand_off && n_level > kExportMinPaths) ? (small_scene ? 64u : ptk::kBlock) : 1u;
             for (int k = 0; k < 4; ++k) {
                 a.ovf_out.q[k] = hand_off ? c->ovf[level & 1][k].p : nullptr;
                 a.ovf_in.q[k] = hand_off ? c->ovf[(level + 1) & 1][k].p : nullptr;

@@ -464,8 +464,8 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     // the next pass reads (from other lanes of this wave -- tiled: of this workgroup) what this pass stored
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     if (!SMALL) __syncthreads();
-    if (SMALL && n_in < a.export_below) break;       // export_below >= 1: an empty segment always ends the wave
-    }   // pass loop
+    if (n_in < a.export_below) break;      // export_below >= 1: an empty segment always ends the wave (tiled:
+    }   // pass loop                       // n_in and export_below are workgroup-uniform)
 
     // Tail hand-off.  Below one chunk a wave would run every further pass mostly empty (and one path trapped
     // in a glass sphere keeps it alive for 50 passes).  Instead it appends what is left to the global
@@ -478,6 +478,15 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
         if (lane < n_in) {
 #pragma unroll 1
             for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + lane]; a.ovf_out.q[k][base + lane] = t; }
+        }
+    }
+    if (!SMALL && n_in != 0u) {            // tiled: the workgroup exports its shared segment (< 256 paths)
+        if (threadIdx.x == 0u) s_iters[0] = atomicAdd(a.ovf_out_count, n_in);
+        __syncthreads();
+        const uint32_t base = s_iters[0];
+        if (threadIdx.x < n_in) {
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + threadIdx.x]; a.ovf_out.q[k][base + threadIdx.x] = t; }
         }
     }
     if (lane == 0u) {
@@ -499,15 +508,17 @@ using namespace PTK_IMPL;
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
     const bool small = a.sc.n_objs <= kSmallObjs;
     const bool mis = a.integrator == 0;
-    const bool ovf = a.src_mode != 0u;     // continuation launches exist for small scenes only
+    const bool ovf = a.src_mode != 0u;     // continuation launch
     const size_t lds = scene_lds_bytes(a.sc);
     const dim3 g(grid), b(kBlock);
     if (small && mis && !ovf) hipLaunchKernelGGL((k_paths<true, true, false>), g, b, lds, st, a);
     else if (small && mis) hipLaunchKernelGGL((k_paths<true, true, true>), g, b, lds, st, a);
     else if (small && !ovf) hipLaunchKernelGGL((k_paths<true, false, false>), g, b, lds, st, a);
     else if (small) hipLaunchKernelGGL((k_paths<true, false, true>), g, b, lds, st, a);
-    else if (mis) hipLaunchKernelGGL((k_paths<false, true, false>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_paths<false, false, false>), g, b, lds, st, a);
+    else if (mis && !ovf) hipLaunchKernelGGL((k_paths<false, true, false>), g, b, lds, st, a);
+    else if (mis) hipLaunchKernelGGL((k_paths<false, true, true>), g, b, lds, st, a);
+    else if (!ovf) hipLaunchKernelGGL((k_paths<false, false, false>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_paths<false, false, true>), g, b, lds, st, a);
 }
 }  // namespace ptk
 namespace PTK_IMPL {
