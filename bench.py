@@ -157,7 +157,8 @@ def main():
     lin = torch.empty((rows, WIDTH, 3), dtype=torch.float32, device=dev)
     rgba = torch.empty((rows, WIDTH, 4), dtype=torch.uint8, device=dev)
 
-    acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0}
+    acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0,
+           "p_vertices": 0, "p_ms": 0.0, "p_launches": 0}
 
     def step(record):
         ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
@@ -173,6 +174,9 @@ def main():
             acc["bounce_ms"] += st.bounce_kernel_ms
             acc["launches"] += st.bounce_launches
             acc["total_ms"] += st.total_ms
+            acc["p_vertices"] += st.primary_vertices
+            acc["p_ms"] += st.primary_kernel_ms
+            acc["p_launches"] += st.primary_launches
         return frame, frame8
 
     def barrier():
@@ -204,8 +208,10 @@ def main():
             assert frame is not None and tuple(frame.shape) == (HEIGHT, WIDTH, 3) and torch.isfinite(frame).all()
         else:
             assert torch.isfinite(lin).all()
-        alg_bytes = BYTES_PER_VERTEX * acc["vertices"] + BYTES_PER_SAMPLE * acc["samples"]
-        achieved = alg_bytes / (acc["bounce_ms"] * 1e-3) / 1e9 if acc["bounce_ms"] > 0 else 0.0
+        # the dominant kernel = the level-0 launch of each batch (camera rays + every bounce until its waves hand
+        # their sparse tails over); it processes p_vertices of the vertices and all of the camera samples
+        alg_bytes = BYTES_PER_VERTEX * acc["p_vertices"] + BYTES_PER_SAMPLE * acc["samples"]
+        achieved = alg_bytes / (acc["p_ms"] * 1e-3) / 1e9 if acc["p_ms"] > 0 else 0.0
         out = {
             "metric": "Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2"
                       else f"Msamples/sec (pixels x spp / s) at {WIDTH}x{HEIGHT}/{SPP}spp",
@@ -229,16 +235,19 @@ def main():
                                                           f"one {args.backend} gather of the f32 + RGBA8 frame to rank 0",
             },
             "roofline": {
-                "kernel": "k_paths (one launch per sample batch: every bounce of every path), rank 0",
+                "kernel": "k_paths<SMALL, MIS, OVF=false>: the level-0 launch of a sample batch (camera rays + every "
+                          "bounce until the waves hand over their sparse tails), rank 0",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(world, args.workload),
-                "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["launches"], 1)),
-                "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 4),
-                "launches": acc["launches"],
+                "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["p_launches"], 1)),
+                "avg_launch_ms": round(acc["p_ms"] / max(acc["p_launches"], 1), 4),
+                "launches": acc["p_launches"],
+                "vertex_share": round(acc["p_vertices"] / max(acc["vertices"], 1), 4),
+                "all_path_kernels_ms_per_step": round(acc["bounce_ms"] / max(args.steps, 1), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

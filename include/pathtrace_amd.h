@@ -120,6 +120,13 @@ typedef struct {
     double   bounce_kernel_ms; /* sum of HIP-event durations of the path-kernel
                                   launches (profile=1), else 0                */
     double   total_ms;         /* HIP-event duration of the whole render      */
+    /* The dominant kernel on its own: the level-0 launch of every batch (the launch that generates the
+     * camera rays and traces them until its waves hand their sparse tails over; the continuation
+     * launches that finish those tails are the rest of bounce_kernel_ms).                          */
+    uint64_t primary_vertices; /* vertices processed by the level-0 launches                      */
+    double   primary_kernel_ms;/* sum of their HIP-event durations (profile=1)                    */
+    uint32_t primary_launches;
+    uint32_t reserved2;
 } PtStats;
 
 /* ---- helpers ------------------------------------------------------------ */

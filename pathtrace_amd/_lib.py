@@ -62,6 +62,10 @@ class PtStats(C.Structure):
         ("reserved", C.c_uint32),
         ("bounce_kernel_ms", C.c_double),
         ("total_ms", C.c_double),
+        ("primary_vertices", C.c_uint64),
+        ("primary_kernel_ms", C.c_double),
+        ("primary_launches", C.c_uint32),
+        ("reserved2", C.c_uint32),
     ]
 
 

@@ -94,6 +94,7 @@ struct PtContext {
     PtStats stats{};
     bool stats_pending = false;
     uint32_t profiled_batches = 0;
+    std::vector<uint32_t> primary_events;      // launch indices of the level-0 launches
     // progressive rendering (pt_render_progressive): carry the f64 film sums across calls
     bool prog_load = false, prog_store = false;
     uint32_t prog_div = 0;
@@ -380,6 +381,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(c->ev_begin, st));
     uint32_t launches = 0;
+    c->primary_events.clear();
 
     for (uint32_t batch = 0; batch < n_batches; ++batch) {
         const uint32_t s0 = batch * nb_max;
@@ -415,6 +417,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             else ptk::launch_paths_fast(a, g, st);
             if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * launches + 1], st));
             HIP_TRY(hipGetLastError());
+            if (level == 0) c->primary_events.push_back(launches);
             ++launches;
             n_level = 0;
             if (a.export_below > 1u) {       // how many paths were handed off?
@@ -441,6 +444,8 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     c->stats.samples = (uint64_t)np * prm->spp;
     c->stats.bounce_launches = launches;
     c->stats.batches = n_batches;
+    c->stats.primary_launches = (uint32_t)c->primary_events.size();
+
     c->profiled_batches = profile ? launches : 0;
     c->stats_pending = true;
     return PT_OK;
@@ -459,6 +464,12 @@ int pt_sync(PtContext* c) {
         c->stats.bounce_kernel_ms = kms;
         c->stats.shadow_rays = c->h_dstats[0];
         c->stats.vertices = c->h_dstats[1];
+        c->stats.primary_vertices = c->h_dstats[3];
+        double pms = 0.0;
+        if (c->profiled_batches)
+            for (uint32_t li : c->primary_events)
+                if (hipEventElapsedTime(&ms, c->ev_pool[2 * li], c->ev_pool[2 * li + 1]) == hipSuccess) pms += ms;
+        c->stats.primary_kernel_ms = pms;
         c->stats.max_depth_reached = (uint32_t)c->h_dstats[2];
         c->stats_pending = false;
     }

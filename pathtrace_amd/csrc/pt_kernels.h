@@ -62,7 +62,7 @@ struct BounceArgs {
     uint32_t export_below;    // >= 1; 1 = never export (a wave runs until its segment is empty)
     uint32_t seg_cap;         // slots per segment (multiple of 64)
     float4* lsamp;            // per-path final radiance, index = s_local*np + tile_row*width + x
-    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)
+    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)  [3] vertices of level-0 launches
     TileMap tile;
     SceneView sc;
     CameraF cam;

@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
         // totals for the host: shadow rays, vertices (= loop iterations summed over paths), deepest vertex
         if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
+        if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);   // level-0 launches only
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
     }
 }
