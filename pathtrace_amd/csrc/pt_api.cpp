@@ -63,7 +63,10 @@ constexpr uint32_t kMinGrid = 256 * 8;         // at least two rounds of 4 resid
 // exports its leftovers to the overflow queue instead of walking them alone; the next launch takes them up.
 // Measured (C2 / C1 ms per 1024^2 x 64 render): no hand-off 10.33 / 18.5; threshold 2^18 (3-4 levels) 11.2 / 16.9;
 // 2^22 (2 levels) 10.28 / 15.65; exporting below 32 or 16 paths instead of 64 is slower.
-constexpr uint32_t kExportMinPaths = 1u << 22;
+#ifndef PT_EXPORT_MIN_LOG2
+#define PT_EXPORT_MIN_LOG2 22
+#endif
+constexpr uint32_t kExportMinPaths = 1u << PT_EXPORT_MIN_LOG2;
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
 
 }  // namespace
