@@ -173,7 +173,9 @@ int pt_scene_upload(PtContext* ctx, const PtObject* objs, uint32_t n_objs);
  *                 src/world.rs:318-319)
  *   d_rgba8:      uint8[tile_rows*W*4], sqrt-gamma + truncation (= World.data /
  *                 draw(), src/world.rs:322-341); may be NULL.
- * Asynchronous on the context's stream; pt_sync() waits.                      */
+ * Work is enqueued on the context's stream; the call returns once the last launch is
+ * enqueued (it synchronises internally once per sample batch, where the tail of the
+ * level-0 launch is handed to a continuation launch).  pt_sync() waits for the rest.   */
 int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
                      float* d_linear_rgb, uint8_t* d_rgba8);
 int pt_sync(PtContext* ctx);
