@@ -120,7 +120,7 @@ def main():
     import torch
     import torch.distributed as dist
     import pathtrace_amd as pt
-    from pathtrace_amd.dist import default_band_rows, gather_tiles
+    from pathtrace_amd.dist import default_band_rows, gather_film
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -165,8 +165,8 @@ def main():
         ctx.sync()
         frame = frame8 = None
         if world > 1:
-            frame = gather_tiles(lin.to(comm_dev), HEIGHT, band_rows, rank, world)
-            frame8 = gather_tiles(rgba.to(comm_dev), HEIGHT, band_rows, rank, world)
+            # the single exchange step of the path: one gather of the framebuffer (f32 + RGBA8 packed)
+            frame, frame8 = gather_film(lin.to(comm_dev), rgba.to(comm_dev), HEIGHT, band_rows, rank, world)
         if record:
             st = ctx.stats()
             acc["vertices"] += st.vertices
@@ -232,7 +232,7 @@ def main():
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
                 "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "
-                                                          f"one {args.backend} gather of the f32 + RGBA8 frame to rank 0",
+                                                          f"ONE {args.backend} gather of the packed f32 + RGBA8 frame to rank 0 per step",
             },
             "roofline": {
                 "kernel": "k_paths<SMALL, MIS, OVF=false>: the level-0 launch of a sample batch (camera rays + every "

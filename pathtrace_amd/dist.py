@@ -44,12 +44,27 @@ def gather_tiles(tile, height, band_rows, rank, world_size, group=None, dst=0):
     return frame
 
 
+def gather_film(lin, rgba, height, band_rows, rank, world_size, group=None, dst=0):
+    """ONE collective for both film planes: the f32 linear plane [rows, W, 3] and the RGBA8 plane
+    [rows, W, 4] are packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel), gathered once and
+    unpacked on `dst`.  Returns (linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`, (None, None) elsewhere."""
+    rows, width = lin.shape[0], lin.shape[1]
+    packed = torch.empty((rows, width, 16), dtype=torch.uint8, device=lin.device)
+    packed[..., :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(rows, width, 12)
+    packed[..., 12:] = rgba
+    frame = gather_tiles(packed, height, band_rows, rank, world_size, group, dst)
+    if frame is None:
+        return None, None
+    lin_full = frame[..., :12].contiguous().reshape(-1).view(torch.float32).reshape(height, width, 3)
+    return lin_full, frame[..., 12:].contiguous()
+
+
 def render_distributed(ctx, cam, params, rank, world_size, band_rows=None, group=None, want_rgba=True):
     """Render this rank's interleaved bands on its GPU and gather the frame(s) on rank 0."""
     params.band_rows = band_rows or default_band_rows(cam.height, world_size)
     params.band_index = rank
     params.band_count = world_size
     lin, rgba = ctx.render(cam, params, want_rgba=want_rgba)
-    frame = gather_tiles(lin, cam.height, params.band_rows, rank, world_size, group)
-    frame8 = gather_tiles(rgba, cam.height, params.band_rows, rank, world_size, group) if want_rgba else None
-    return frame, frame8
+    if want_rgba:
+        return gather_film(lin, rgba, cam.height, params.band_rows, rank, world_size, group)
+    return gather_tiles(lin, cam.height, params.band_rows, rank, world_size, group), None

@@ -29,13 +29,19 @@ def _worker(rank, world, port, H, W, band_rows, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import pathtrace_amd as pt
-    from pathtrace_amd.dist import gather_tiles
+    from pathtrace_amd.dist import gather_film, gather_tiles
     from oracle import orc
     cam = pt.camera_new(width=W, height=H)
     prm = pt.default_params(spp=2, band_rows=band_rows, band_index=rank, band_count=world)
     lin, rgba, _ = orc.render(cam, pt.builtin_scene(1), prm, orc.F32, orc.ITERATIVE)
     frame = gather_tiles(torch.from_numpy(lin.astype(np.float32)), H, band_rows, rank, world)
     frame8 = gather_tiles(torch.from_numpy(rgba), H, band_rows, rank, world)
+    # the packed single-collective form bench.py uses must give the same two planes
+    pf, p8 = gather_film(torch.from_numpy(lin.astype(np.float32)), torch.from_numpy(rgba), H, band_rows, rank, world)
+    if rank == 0:
+        assert torch.equal(pf, frame) and torch.equal(p8, frame8)
+    else:
+        assert pf is None and p8 is None
     dist.barrier()
     if rank == 0:
         np.savez(out_path, lin=frame.numpy(), rgba=frame8.numpy())
