@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0, help="PtRenderParams.max_paths_in_flight (0 = default)")
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--accel", type=int, default=0, choices=[0, 1],
+                    help="PtRenderParams.accel: 0 = the reference's linear scan (every reported config), 1 = BVH (same film)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
                          "goes through host memory); the driver's runs use nccl (RCCL)")
@@ -149,7 +151,7 @@ def main():
     spp = SPP * world
     band_rows = default_band_rows(HEIGHT, world) if world > 1 else 0
     prm = pt.default_params(spp=spp, band_rows=band_rows, band_index=rank, band_count=world, profile=1,
-                            max_paths_in_flight=args.max_paths, workgroups=args.workgroups)
+                            max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
     ctx = pt.Context(dev_index)
     ctx.upload(objs)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -229,6 +231,7 @@ def main():
             "config": {
                 "workload": f"{wl_desc}, {WIDTH}x{HEIGHT}, {spp} spp "
                             f"({SPP} spp per GPU), MIS, min_depth 4 / max_depth 50",
+                "hit_scene": "BVH traversal (accel=1, same film as the linear scan)" if args.accel else "linear scan (reference)",
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
                 "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "

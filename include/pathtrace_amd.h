@@ -104,7 +104,12 @@ typedef struct {
      * is bit-identical to the f32 CPU oracle, and the render is ~1.3x slower.  Both modes meet the
      * FP32 tolerance against the f64 reference arithmetic.                      */
     uint32_t exact_math;
-    uint32_t reserved;
+    /* How World::hit_scene (world.rs:270-290) finds the closest hit.  0 (default): the reference's linear
+     * scan over all objects.  1: traversal of a BVH over the objects' bounding boxes, built on the host the
+     * first time a render asks for it (beyond the reference).  The BVH only prunes the scan:
+     * the primitive tests and the winner (smallest t; among equal t the highest object index) are those of
+     * the linear scan, and the film is identical.  Worth it for scenes of hundreds of objects and more.    */
+    uint32_t accel;
 } PtRenderParams;
 
 /* Counters of the last render on a context. */
@@ -206,7 +211,8 @@ int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n_objs,
  * direction is normalised on entry like Ray::new, src/camera.rs:10-16).
  * out_id[i] = object index or -1, out_t[i] = hit distance.                   */
 int pt_debug_hit_scene(PtContext* ctx, const double* rays, uint32_t n,
-                       double t_min, double t_max, uint32_t exact_math, int32_t* out_id, float* out_t);
+                       double t_min, double t_max, uint32_t exact_math, uint32_t accel,
+                       int32_t* out_id, float* out_t);
 
 const char* pt_last_error(void);
 uint32_t pt_abi_version(void);

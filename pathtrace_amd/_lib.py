@@ -47,7 +47,7 @@ class PtRenderParams(C.Structure):
         ("profile", C.c_uint32),
         ("workgroups", C.c_uint32),
         ("exact_math", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("accel", C.c_uint32),
     ]
 
 
@@ -94,7 +94,7 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double, C.c_uint32,
-                                     _P(C.c_int32), _P(C.c_float)]),
+                                     C.c_uint32, _P(C.c_int32), _P(C.c_float)]),
     "pt_last_error": (C.c_char_p, []),
     "pt_abi_version": (C.c_uint32, []),
 }

@@ -140,12 +140,12 @@ class Context:
                                           lin.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p)))
         return lin, rgba
 
-    def debug_hit_scene(self, rays, t_min=0.001, t_max=float("inf"), exact_math=0):
+    def debug_hit_scene(self, rays, t_min=0.001, t_max=float("inf"), exact_math=0, accel=0):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = rays.shape[0]
         ids = np.empty(n, dtype=np.int32)
         ts = np.empty(n, dtype=np.float32)
-        check(lib().pt_debug_hit_scene(self._h, rays.ctypes.data_as(C.POINTER(C.c_double)), n, t_min, t_max, exact_math,
+        check(lib().pt_debug_hit_scene(self._h, rays.ctypes.data_as(C.POINTER(C.c_double)), n, t_min, t_max, exact_math, accel,
                                        ids.ctypes.data_as(C.POINTER(C.c_int32)),
                                        ts.ctypes.data_as(C.POINTER(C.c_float))))
         return ids, ts

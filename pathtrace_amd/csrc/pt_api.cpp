@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/pathtrace_amd.h"
+#include "pt_bvh.h"
 #include "pt_kernels.h"
 
 namespace {
@@ -81,6 +82,13 @@ struct PtContext {
     DevBuf<uint32_t> lights;
     ptk::SceneView view{};
     bool has_scene = false;
+    // BVH (PtRenderParams.accel): built from the host copy of the shape records at first use
+    std::vector<float4> h_shape;
+    std::vector<uint32_t> h_shape_tag;
+    DevBuf<float4> bvh_nodes, bvh_rec;
+    DevBuf<uint32_t> bvh_ids;
+    bool has_bvh = false;
+    uint32_t bvh_depth = 0;
     // wavefront state
     DevBuf<float4> queue[4];
     DevBuf<float4> ovf[2][4];         // overflow queues of the tail hand-off (ping-pong between launches)
@@ -124,6 +132,29 @@ std::vector<uint32_t> tile_row_list(uint32_t height, uint32_t band_rows, uint32_
 }
 
 float4 f4(double a, double b, double c, double d) { return make_float4((float)a, (float)b, (float)c, (float)d); }
+
+// Build and upload the BVH of the uploaded scene (once per scene).
+int ensure_bvh(PtContext* c) {
+    if (c->has_bvh) return PT_OK;
+    if (c->view.n_objs >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "accel: %u objects exceed the 2^28 leaf slots", c->view.n_objs);
+    ptbvh::Built b = ptbvh::build(c->h_shape.data(), c->h_shape_tag.data(), c->view.n_objs);
+    static_assert(ptbvh::kStackDepth == ptk::kBvhStack, "traversal stack depth");
+    if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
+    int rc;
+    if ((rc = c->bvh_nodes.ensure(b.nodes.size() + 4)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
+        (rc = c->bvh_ids.ensure(b.leaf_ids.size() + 1)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!b.nodes.empty()) HIP_TRY(hipMemcpy(c->bvh_nodes.p, b.nodes.data(), b.nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!b.leaf_rec.empty()) HIP_TRY(hipMemcpy(c->bvh_rec.p, b.leaf_rec.data(), b.leaf_rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!b.leaf_ids.empty()) HIP_TRY(hipMemcpy(c->bvh_ids.p, b.leaf_ids.data(), b.leaf_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->view.bvh.nodes = c->bvh_nodes.p; c->view.bvh.rec = c->bvh_rec.p; c->view.bvh.ids = c->bvh_ids.p;
+    c->view.bvh.root = b.root;
+    c->view.bvh.scene_abs = b.scene_abs;
+    c->bvh_depth = b.depth;
+    c->has_bvh = true;
+    return PT_OK;
+}
 
 }  // namespace
 
@@ -184,6 +215,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
+    c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release();
     for (auto& b : c->queue) b.release();
     for (auto& q : c->ovf) for (auto& b : q) b.release();
     c->ovf_count.release();
@@ -291,6 +323,11 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     }
     c->view.scan_f4 = (uint32_t)scan.size();
     c->view.n_runs = (uint32_t)runs.size(); c->view.n_objs = n; c->view.n_lights = (uint32_t)lights.size();
+    c->view.bvh = ptk::BvhView{};
+    c->has_bvh = false;
+    c->h_shape.assign(shape.begin(), shape.begin() + 3 * (size_t)n);
+    c->h_shape_tag.resize(n);
+    for (uint32_t i = 0; i < n; ++i) c->h_shape_tag[i] = objs[i].shape_tag;
     c->has_scene = true;
     return PT_OK;
 }
@@ -302,6 +339,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         return fail(PT_ERR_INVALID_ARG, "camera %ux%u: width and height must be >= 2", cam->width, cam->height);
     if (prm->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
     if (prm->integrator > PT_INTEGRATOR_BRDF_ONLY) return fail(PT_ERR_INVALID_ARG, "unknown integrator %u", prm->integrator);
+    if (prm->accel > 1u) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", prm->accel);
     const uint32_t band_count = prm->band_count ? prm->band_count : 1;
     if (prm->band_index >= band_count) return fail(PT_ERR_INVALID_ARG, "band_index %u >= band_count %u", prm->band_index, band_count);
     HIP_TRY(hipSetDevice(c->device));
@@ -339,13 +377,14 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const uint32_t nw = grid * kWavesPerBlock;
     const uint32_t seg_cap = ((chunks_max + nw - 1) / nw) * 64u;
     const bool hand_off = true;
-    const bool small_scene = c->view.n_objs <= ptk::kSmallObjs;     // tiled scenes export per workgroup (< 256 paths)
+    const bool small_scene = c->view.n_objs <= ptk::kSmallObjs || prm->accel;     // the tiled scan exports per workgroup (< 256 paths)
     const uint32_t nw_cont = std::max(nw, kMinGrid * kWavesPerBlock);    // waves of any continuation launch
     const size_t ovf_slots = (size_t)nw_cont * 64u;                      // a wave exports < 64 paths (a workgroup < 256)
     // level 0 needs nw*seg_cap slots; a continuation launch of n <= nw*63 paths needs <= n + 64 + nw_cont*64
     const size_t q_slots = std::max((size_t)nw * seg_cap, (size_t)nw * 63u + 64u + (size_t)nw_cont * 64u);
 
     int rc;
+    if (prm->accel && (rc = ensure_bvh(c))) return rc;
     for (int k = 0; k < 4; ++k)
         if ((rc = c->queue[k].ensure(q_slots))) return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
@@ -379,6 +418,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     a.min_depth = prm->min_depth; a.max_depth = prm->max_depth;
     a.t_min = (float)prm->t_min;
     a.integrator = prm->integrator;
+    a.accel = prm->accel;
 
     const bool profile = prm->profile != 0;
     HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
@@ -488,11 +528,13 @@ int pt_get_stats(PtContext* c, PtStats* out) {
 }
 
 int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, uint32_t exact_math,
-                       int32_t* out_id, float* out_t) {
+                       uint32_t accel, int32_t* out_id, float* out_t) {
     if (!c || !rays || !out_id || !out_t) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
+    if (accel > 1u) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", accel);
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
+    if (accel) { int rb = ensure_bvh(c); if (rb) return rb; }
     std::vector<float> r6(6 * (size_t)n);
     for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];
     DevBuf<float> d_r, d_t;
@@ -501,8 +543,8 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
     int rc;
     if ((rc = d_r.ensure(r6.size())) || (rc = d_id.ensure(n)) || (rc = d_t.ensure(n))) return rc;
     HIP_TRY(hipMemcpy(d_r.p, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (exact_math) ptk::launch_debug_hit_exact(c->view, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
-    else ptk::launch_debug_hit_fast(c->view, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
+    if (exact_math) ptk::launch_debug_hit_exact(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
+    else ptk::launch_debug_hit_fast(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_id, d_id.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -1,0 +1,183 @@
+// pt_bvh.cpp -- host-side BVH builder (see pt_bvh.h).  Binned SAH near the root, object-median
+// splits wherever SAH could make the tree deeper than the traversal stack.
+#include "pt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace ptbvh {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; } }
+    void grow(const Box& b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    double half_area() const {
+        double e[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+        if (e[0] < 0 || e[1] < 0 || e[2] < 0) return 0.0;
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    }
+};
+
+float down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -std::numeric_limits<float>::infinity()) : f; }
+float up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, std::numeric_limits<float>::infinity()) : f; }
+
+struct Prim {
+    Box box;
+    float cen[3];
+    uint32_t obj;
+};
+
+// levels an object-median subtree of m primitives needs below its root
+uint32_t median_levels(uint64_t m) {
+    uint32_t l = 0;
+    while (m > kMaxLeaf) { m = (m + 1) / 2; ++l; }
+    return l;
+}
+
+constexpr uint32_t kMaxDepth = kStackDepth - 2;   // deepest leaf the traversal stack (sentinel + one push per level) can take
+constexpr int kBins = 16;
+
+struct Builder {
+    std::vector<Prim> prims;
+    const float4* shape;
+    const uint32_t* tag;
+    Built out;
+
+    uint32_t make_leaf(uint32_t first, uint32_t count, uint32_t depth) {
+        const uint32_t slot = (uint32_t)out.leaf_ids.size();
+        // object order inside a leaf (not needed for correctness, keeps the tests in scan order)
+        std::sort(prims.begin() + first, prims.begin() + first + count, [](const Prim& a, const Prim& b) { return a.obj < b.obj; });
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t o = prims[first + i].obj;
+            const bool tri = tag[o] != 0;
+            out.leaf_ids.push_back(o | (tri ? kTriangleBit : 0u));
+            float4 r0 = shape[3 * (size_t)o], r1 = shape[3 * (size_t)o + 1], r2 = shape[3 * (size_t)o + 2];
+            if (!tri) { r0.w = r0.w * r0.w; r1 = make_float4(0, 0, 0, 0); r2 = r1; }   // (c, r^2): the scan record of a sphere
+            out.leaf_rec.push_back(r0); out.leaf_rec.push_back(r1); out.leaf_rec.push_back(r2);
+        }
+        out.depth = std::max(out.depth, depth);
+        return kLeafBit | ((count - 1u) << 28) | slot;
+    }
+
+    // returns the child code of the subtree over prims[first, first+count)
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, Box* box_out) {
+        Box box; box.reset();
+        Box cb; cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            box.grow(prims[i].box);
+            for (int k = 0; k < 3; ++k) { cb.lo[k] = std::min(cb.lo[k], prims[i].cen[k]); cb.hi[k] = std::max(cb.hi[k], prims[i].cen[k]); }
+        }
+        *box_out = box;
+        if (count <= kMaxLeaf) return make_leaf(first, count, depth);
+
+        uint32_t mid = 0;
+        bool split = false;
+        if (depth + 1u + median_levels(count - 1u) <= kMaxDepth) {   // SAH may be arbitrarily unbalanced: only while that is safe
+            double best = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_bin = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                const double lo = cb.lo[ax], ext = (double)cb.hi[ax] - lo;
+                if (!(ext > 0.0)) continue;
+                Box bb[kBins]; uint32_t bn[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bn[b] = 0; }
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = (int)(((double)prims[i].cen[ax] - lo) / ext * kBins);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    bb[b].grow(prims[i].box); bn[b]++;
+                }
+                double right_area[kBins]; uint32_t right_n[kBins];
+                Box acc; acc.reset(); uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); n += bn[b]; right_area[b] = acc.half_area(); right_n[b] = n; }
+                acc.reset(); n = 0;
+                for (int b = 0; b + 1 < kBins; ++b) {
+                    acc.grow(bb[b]); n += bn[b];
+                    if (n == 0 || right_n[b + 1] == 0) continue;
+                    const double cost = acc.half_area() * n + right_area[b + 1] * right_n[b + 1];
+                    if (cost < best) { best = cost; best_axis = ax; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const double lo = cb.lo[best_axis], ext = (double)cb.hi[best_axis] - lo;
+                auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+                    int b = (int)(((double)p.cen[best_axis] - lo) / ext * kBins);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - prims.begin());
+                split = mid > first && mid < first + count;
+            }
+        }
+        if (!split) {   // object median along the widest centroid axis (or any axis when all centroids coincide)
+            int ax = 0;
+            double e = -1.0;
+            for (int k = 0; k < 3; ++k) { const double x = (double)cb.hi[k] - cb.lo[k]; if (x > e) { e = x; ax = k; } }
+            mid = first + (count + 1u) / 2u;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                             [ax](const Prim& a, const Prim& b) { return a.cen[ax] < b.cen[ax] || (a.cen[ax] == b.cen[ax] && a.obj < b.obj); });
+        }
+        const uint32_t node = (uint32_t)(out.nodes.size() / 4);
+        out.nodes.resize(out.nodes.size() + 4);
+        Box b0, b1;
+        const uint32_t c0 = build(first, mid - first, depth + 1, &b0);
+        const uint32_t c1 = build(mid, first + count - mid, depth + 1, &b1);
+        float cb0, cb1;
+        std::memcpy(&cb0, &c0, 4); std::memcpy(&cb1, &c1, 4);
+        out.nodes[4 * (size_t)node + 0] = make_float4(b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]);
+        out.nodes[4 * (size_t)node + 1] = make_float4(b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]);
+        out.nodes[4 * (size_t)node + 2] = make_float4(b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]);
+        out.nodes[4 * (size_t)node + 3] = make_float4(cb0, cb1, 0.f, 0.f);
+        return node;
+    }
+};
+
+}  // namespace
+
+Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n) {
+    Builder b;
+    b.shape = shape; b.tag = shape_tag;
+    b.prims.resize(n);
+    double amax[3] = {0, 0, 0};
+    for (uint32_t i = 0; i < n; ++i) {
+        Prim& p = b.prims[i];
+        p.obj = i;
+        const float4 r0 = shape[3 * (size_t)i], r1 = shape[3 * (size_t)i + 1], r2 = shape[3 * (size_t)i + 2];
+        if (shape_tag[i] == 0) {
+            // the scan tests against r2 = fl(r*r); bound the sphere of radius sqrt(r2), rounded outward
+            const float r2f = r0.w * r0.w;
+            const double r = std::sqrt((double)r2f) * (1.0 + 1e-7);
+            const double c[3] = {r0.x, r0.y, r0.z};
+            for (int k = 0; k < 3; ++k) { p.box.lo[k] = down(c[k] - r); p.box.hi[k] = up(c[k] + r); }
+        } else {
+            const double v0[3] = {r0.x, r0.y, r0.z}, e1[3] = {r1.x, r1.y, r1.z}, e2[3] = {r2.x, r2.y, r2.z};
+            for (int k = 0; k < 3; ++k) {
+                const double a = v0[k], bq = v0[k] + e1[k], c = v0[k] + e2[k];
+                p.box.lo[k] = down(std::min(a, std::min(bq, c)));
+                p.box.hi[k] = up(std::max(a, std::max(bq, c)));
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            // a non-finite box (NaN/inf object) would poison every ancestor: make it cover everything instead
+            if (!(std::isfinite(p.box.lo[k]) && std::isfinite(p.box.hi[k]))) {
+                p.box.lo[k] = -std::numeric_limits<float>::max(); p.box.hi[k] = std::numeric_limits<float>::max();
+                p.cen[k] = 0.f;
+            } else {
+                p.cen[k] = (float)(0.5 * ((double)p.box.lo[k] + p.box.hi[k]));
+                amax[k] = std::max(amax[k], std::max(std::fabs((double)p.box.lo[k]), std::fabs((double)p.box.hi[k])));
+            }
+        }
+    }
+    b.out.nodes.reserve(4 * (size_t)n);
+    b.out.leaf_ids.reserve(n);
+    b.out.leaf_rec.reserve(3 * (size_t)n);
+    if (n != 0) {
+        Box root;
+        b.out.root = b.build(0, n, 0, &root);
+    }
+    b.out.scene_abs = up(amax[0] + amax[1] + amax[2]);
+    return std::move(b.out);
+}
+
+}  // namespace ptbvh

@@ -1,0 +1,39 @@
+// pt_bvh.h -- optional acceleration structure for World::hit_scene (the reference
+// itself is linear-scan only, world.rs:281).  A binary BVH over the objects' f32 bounding boxes,
+// built on the host at first use.  It only decides WHICH primitives a ray is tested against; the
+// primitive tests are the ones of the linear scan, and the winner is chosen by the rule the scan
+// implies (smallest t; among equal t the highest object index), so the answer does not depend on
+// the traversal order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace ptbvh {
+
+// Child code of a node: bit 31 clear = index of an internal node; bit 31 set = leaf with
+// ((code >> 28) & 7) + 1 primitives starting at slot (code & 0x0FFFFFFF) of the leaf arrays.
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kDone = 0xFFFFFFFFu;      // stack sentinel / root of an empty scene (no leaf code: a leaf holds <= 4 primitives)
+constexpr uint32_t kMaxLeaf = 4;             // primitives per leaf
+constexpr uint32_t kStackDepth = 32;         // traversal stack entries per lane (LDS); the builder keeps the tree this shallow
+constexpr uint32_t kTriangleBit = 0x80000000u;   // in leaf_ids: the primitive is a triangle
+
+struct Built {
+    // internal node k = nodes[4k .. 4k+3]:
+    //   n0 = (lo0.x, lo0.y, lo0.z, hi0.x)  n1 = (hi0.y, hi0.z, lo1.x, lo1.y)  n2 = (lo1.z, hi1.x, hi1.y, hi1.z)
+    //   n3 = (bits child0, bits child1, 0, 0)
+    std::vector<float4> nodes;
+    std::vector<float4> leaf_rec;     // 3 float4 per leaf slot: sphere (c, r^2), -, - ; triangle v0, e1, e2 (the scan records)
+    std::vector<uint32_t> leaf_ids;   // object index of the leaf slot (| kTriangleBit)
+    uint32_t root = kDone;            // child code of the root
+    uint32_t depth = 0;               // deepest leaf (root = 0)
+    float scene_abs = 0.0f;           // sum over axes of the largest |coordinate| of any box: scale of the traversal padding
+};
+
+// shape: 3 float4 per object in the gather form of pt_device.h (sphere: (c, r), (1/r,..), -; triangle: v0, e1, e2);
+// scan_w: for spheres the r^2 the scan record carries.  Throws nothing; n may be 0.
+Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n);
+
+}  // namespace ptbvh

@@ -16,6 +16,15 @@ struct Run {
     uint32_t off4;       // offset of the run in the scan array, in float4 units
 };
 
+// Optional BVH over the objects (pt_bvh.h); built on the host the first time a render asks for it.
+struct BvhView {
+    const float4* nodes;     // 4 float4 per internal node: the two child boxes + child codes
+    const float4* rec;       // 3 float4 per leaf slot (scan record of the primitive)
+    const uint32_t* ids;     // object index per leaf slot (bit 31: triangle)
+    uint32_t root;           // child code of the root
+    float scene_abs;         // scale of the padding the slab test applies (see bvh_scan)
+};
+
 struct SceneView {
     const float4* scan;      // scan records, run-packed: sphere = 1 float4 (c, r^2); triangle = 3 float4 (v0, e1, e2)
     const float4* shape;     // 3 float4 per object (gather form), see pt_device.h
@@ -28,6 +37,7 @@ struct SceneView {
     uint32_t blob_f4;        // float4 count of `blob` (0 for larger scenes)
     uint32_t scan_f4;        // float4 count of `scan`
     uint32_t n_runs, n_objs, n_lights;
+    BvhView bvh;             // valid only for launches with accel != 0
 };
 
 struct CameraF {             // Camera's cached fields in f32 (camera.rs:36-38)
@@ -72,6 +82,7 @@ struct BounceArgs {
     uint32_t min_depth, max_depth;
     float t_min;
     uint32_t integrator;
+    uint32_t accel;           // 0: linear scan (the reference's hit_scene), 1: BVH traversal, same answers
 };
 
 constexpr uint32_t kBlock = 256;
@@ -80,6 +91,7 @@ constexpr uint32_t kBlock = 256;
 // through one LDS tile and gather shape/material records from global memory.
 constexpr uint32_t kSmallObjs = 128;
 constexpr uint32_t kTileF4 = 2550;         // 39.8 KiB LDS tile (divisible by 3: whole triangles); 4 workgroups per CU
+constexpr uint32_t kBvhStack = 32;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 32 KiB per workgroup
 
 // One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
 // (4 queue segments each).  _exact / _fast: the two arithmetic modes of pt_device.h
@@ -104,9 +116,9 @@ struct ResolveArgs {
 void launch_resolve(const ResolveArgs& a, hipStream_t st);
 
 // World::hit_scene on arbitrary rays (debug/parity entry).
-void launch_debug_hit_exact(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max,
+void launch_debug_hit_exact(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min, float t_max,
                             int32_t* out_id, float* out_t, hipStream_t st);
-void launch_debug_hit_fast(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max,
+void launch_debug_hit_fast(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min, float t_max,
                            int32_t* out_id, float* out_t, hipStream_t st);
 
 }  // namespace ptk

@@ -36,6 +36,9 @@ namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ primitive tests
 // SphereShape::hit (shape.rs:53-82) against the running closest t.  s = (center, r^2).
+// ORDERED (BVH traversal, which meets the primitives in tree order): among equal t the highest object index
+// wins -- what the scan's "accept t <= closest" gives when it walks the objects in index order.
+template <bool ORDERED = false>
 PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min, float& closest, int& id, int obj) {
     f3 oc = o - mk(s.x, s.y, s.z);
     float half_b = dot(oc, d);
@@ -53,10 +56,12 @@ PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min,
     // so "closest < root1" already rejects both; hence the candidate is root2 only when root1 < t_min.
     float c = root1 < t_min ? root2 : root1;
     if (c < t_min || closest < c) return;          // NaN is accepted, as in the reference
+    if (ORDERED && c == closest && obj < id) return;
     closest = c;
     id = obj;
 }
 // TriangleShape::hit (shape.rs:161-192), Moeller-Trumbore; e1, e2 precomputed.
+template <bool ORDERED = false>
 PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
     f3 h = cross(d, e2);
     float a = dot(e1, h);
@@ -70,6 +75,7 @@ PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& c
     if (v < 0.0f || u + v > 1.0f) return;
     float t = f * dot(e2, q);
     if (t < t_min || t > closest) return;
+    if (ORDERED && t == closest && obj < id) return;
     closest = t;
     id = obj;
 }
@@ -114,9 +120,13 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
     }
 }
 
-// Where the kernel finds the scene.  SMALL: everything is in LDS (the blob of
-// SceneView, copied once per workgroup).  Otherwise the scan array streams through
-// the LDS tile and the per-object records are gathered from global memory.
+// How a kernel finds the closest hit:
+//   kModeLds    scenes of <= kSmallObjs objects: everything is in LDS (the blob of SceneView, copied once per
+//               workgroup), linear scan
+//   kModeTiled  larger scenes: the scan array streams through one LDS tile (block-uniform loop, barriers), the
+//               per-object records are gathered from global memory, linear scan
+//   kModeBvh    accel = 1: per-lane BVH traversal out of global memory / L2 (stack in LDS, no barriers)
+constexpr int kModeLds = 0, kModeTiled = 1, kModeBvh = 2;
 struct SceneRef {
     const float4* scan;     // SMALL: LDS scan array; else: the LDS tile buffer
     const float4* shape;
@@ -124,14 +134,20 @@ struct SceneRef {
     const Run* runs;
     const uint32_t* lights;
     const float4* scan_global;
+    const Run* runs_global;
     uint32_t n_runs, n_lights;
+    BvhView bvh;
+    uint32_t* stack;        // kModeBvh: LDS traversal stack, entry e of thread t at stack[e * kBlock + t]
 };
-template <bool SMALL>
+template <int MODE>
 PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
     SceneRef r;
     r.n_runs = sc.n_runs; r.n_lights = sc.n_lights;
     r.scan_global = sc.scan;
-    if (SMALL) {
+    r.runs_global = sc.runs;
+    r.bvh = sc.bvh;
+    r.stack = reinterpret_cast<uint32_t*>(lds);
+    if (MODE == kModeLds) {
         for (uint32_t k = threadIdx.x; k < sc.blob_f4; k += kBlock) lds[k] = sc.blob[k];
         __syncthreads();
         r.scan = lds;
@@ -146,12 +162,99 @@ PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
     return r;
 }
 
+// hit_scene by BVH traversal.  Every primitive whose test the linear scan would have accepted is still
+// tested: a subtree is skipped only if the ray misses its box, enlarged by `pad` on every side, inside
+// [t_min, closest].  pad = 2^-15 (|o|_1 + scene extent) is ~100x the rounding error of the primitive tests
+// (their error scales with the distance between ray origin and primitive), so a hit that exists only through
+// rounding (a grazing ray) is inside the padded box as well.  Rays with a non-finite coordinate or a zero
+// direction (the reference lets NaN through its sphere test, Q10) take the linear scan, from global memory.
+// ANY: visibility query -- only "is there a hit" is used, so the lane stops at its first accepted primitive.
+constexpr float kBvhPad = 1.0f / 32768.0f;
+PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out);
+template <bool ANY>
+PT_DEV void bvh_scan(const SceneRef& sc, bool active, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
+    const float a = dot(d, d);
+    const float inv_a = pt_rcp(a);
+    float closest = t_max;
+    int id = -1;
+    const float o1 = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
+    // a regular ray: finite coordinates and 0 < |d|^2 with a finite reciprocal (false for NaN).  normalize() leaves
+    // a zero vector as it is, and a zero direction makes every sphere test NaN (0 * inf) -- the scan's business.
+    const bool finite = o1 + __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) + a + inv_a < kInf;
+    if (active && finite) {
+        const float pad = kBvhPad * (o1 + sc.bvh.scene_abs);
+        const f3 op = mk(o.x + pad, o.y + pad, o.z + pad), om = mk(o.x - pad, o.y - pad, o.z - pad);
+        const f3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // +-inf for a zero component
+        uint32_t* stk = sc.stack + threadIdx.x;
+        stk[0] = 0xFFFFFFFFu;                  // ptbvh::kDone
+        uint32_t sp = 1;
+        uint32_t node = sc.bvh.root;
+        while (node != 0xFFFFFFFFu) {
+            while ((int)node >= 0) {           // internal node: test both child boxes
+                const float4* n = sc.bvh.nodes + 4u * node;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                // slab test; min/max drop the NaN of 0 * inf (ray parallel to a slab, origin on its plane)
+                float ax0 = (n0.x - op.x) * inv.x, ax1 = (n0.w - om.x) * inv.x;
+                float ay0 = (n0.y - op.y) * inv.y, ay1 = (n1.x - om.y) * inv.y;
+                float az0 = (n0.z - op.z) * inv.z, az1 = (n1.y - om.z) * inv.z;
+                const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
+                const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
+                ax0 = (n1.z - op.x) * inv.x; ax1 = (n2.y - om.x) * inv.x;
+                ay0 = (n1.w - op.y) * inv.y; ay1 = (n2.z - om.y) * inv.y;
+                az0 = (n2.x - op.z) * inv.z; az1 = (n2.w - om.z) * inv.z;
+                const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
+                const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+                if (h0 && h1) {
+                    const bool swap = tn1 < tn0;               // nearer child first
+                    stk[sp * kBlock] = swap ? c0 : c1;
+                    ++sp;
+                    node = swap ? c1 : c0;
+                } else if (h0 || h1) {
+                    node = h0 ? c0 : c1;
+                } else {
+                    --sp;
+                    node = stk[sp * kBlock];
+                }
+            }
+            if (node == 0xFFFFFFFFu) break;
+            const uint32_t first = node & 0x0FFFFFFFu, cnt = ((node >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t w = sc.bvh.ids[first + i];
+                const float4* rec = sc.bvh.rec + 3u * (first + i);
+                const float4 r0 = rec[0];
+                if ((int)w >= 0) {
+                    sphere_test<true>(r0, o, d, a, inv_a, t_min, closest, id, (int)w);
+                } else {
+                    const float4 r1 = rec[1], r2 = rec[2];
+                    triangle_test<true>(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), o, d, t_min, closest, id,
+                                        (int)(w & 0x7FFFFFFFu));
+                }
+            }
+            if (ANY && id >= 0) break;
+            --sp;
+            node = stk[sp * kBlock];
+        }
+    }
+    if (__ballot(active && !finite) != 0ull) {
+        if (active && !finite) scan_global(sc, o, d, t_min, t_max, id, closest);
+    }
+    id_out = id;
+    t_out = closest;
+}
+
 // World::hit_scene (world.rs:270-290): linear scan in object order with a
-// shrinking t_max.  SMALL: the whole scan array already sits in LDS.  Otherwise
+// shrinking t_max.  kModeLds: the whole scan array already sits in LDS.  kModeTiled:
 // every run is streamed through one LDS tile; the loop is block-uniform (all
 // threads of the workgroup call this together, active or not).
-template <bool SMALL>
+template <int MODE>
 PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
+    constexpr bool SMALL = MODE == kModeLds;
     float a = dot(d, d);
     float inv_a = pt_rcp(a);
     float closest = t_max;
@@ -173,6 +276,19 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
                 scan_run<true>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
             }
         }
+    }
+    id_out = id;
+    t_out = closest;
+}
+// the same scan with every record read from global memory (no LDS, no barrier: any subset of lanes may call it)
+PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
+    float a = dot(d, d);
+    float inv_a = pt_rcp(a);
+    float closest = t_max;
+    int id = -1;
+    for (uint32_t r = 0; r < sc.n_runs; ++r) {
+        const Run run = sc.runs_global[r];
+        scan_run<false>(sc.scan_global + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
     }
     id_out = id;
     t_out = closest;
@@ -220,11 +336,14 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4      // minimum waves per SIMD the register allocator must leave room for
 #endif
-template <bool SMALL, bool MIS, bool OVF>   // OVF: continuation launch, pass 0 reads the overflow queue
+template <int MODE, bool MIS, bool OVF>   // OVF: continuation launch, pass 0 reads the overflow queue
 __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a) {
+    // SMALL = "the waves of a workgroup are independent" (no barrier inside the scan): wave-private queue
+    // segments.  Only the tiled scan ties the four waves of a workgroup together.
+    constexpr bool SMALL = MODE != kModeTiled;
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
-    const SceneRef sc = stage_scene<SMALL>(a.sc, lds);
+    const SceneRef sc = stage_scene<MODE>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (kBlock / 64);
@@ -331,7 +450,8 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
-        scan_closest<SMALL>(sc, o, d, a.t_min, kInf, id, t);
+        if (MODE == kModeBvh) bvh_scan<false>(sc, active, o, d, a.t_min, kInf, id, t);
+        else scan_closest<MODE>(sc, o, d, a.t_min, kInf, id, t);
         bool alive = active && id >= 0;
 
         Hit hit;
@@ -388,7 +508,8 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
                 f3 sdir = need_shadow ? light_dir : parked_dir();
                 f3 sorg = need_shadow ? hit.point : parked_origin();
                 int sid; float st;
-                scan_closest<SMALL>(sc, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
+                if (MODE == kModeBvh) bvh_scan<true>(sc, need_shadow, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
+                else scan_closest<MODE>(sc, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
                 visible = need_shadow && sid < 0;
                 wave_shadow += (uint32_t)__popcll(__ballot(need_shadow));
             }
@@ -498,28 +619,33 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     }
 }
 
-static size_t scene_lds_bytes(const SceneView& sc) {
-    const bool small = sc.n_objs <= kSmallObjs;
-    return (small ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
+static int scene_mode(const SceneView& sc, uint32_t accel) {
+    return accel ? kModeBvh : (sc.n_objs <= kSmallObjs ? kModeLds : kModeTiled);
+}
+static size_t scene_lds_bytes(const SceneView& sc, int mode) {
+    if (mode == kModeBvh) return (size_t)kBvhStack * kBlock * sizeof(uint32_t);
+    return (mode == kModeLds ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
+}
+template <int MODE>
+static void launch_paths_mode(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
+    const bool mis = a.integrator == 0;
+    const bool ovf = a.src_mode != 0u;     // continuation launch
+    const dim3 g(grid), b(kBlock);
+    if (mis && !ovf) hipLaunchKernelGGL((k_paths<MODE, true, false>), g, b, lds, st, a);
+    else if (mis) hipLaunchKernelGGL((k_paths<MODE, true, true>), g, b, lds, st, a);
+    else if (!ovf) hipLaunchKernelGGL((k_paths<MODE, false, false>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MODE, false, true>), g, b, lds, st, a);
 }
 
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
-    const bool small = a.sc.n_objs <= kSmallObjs;
-    const bool mis = a.integrator == 0;
-    const bool ovf = a.src_mode != 0u;     // continuation launch
-    const size_t lds = scene_lds_bytes(a.sc);
-    const dim3 g(grid), b(kBlock);
-    if (small && mis && !ovf) hipLaunchKernelGGL((k_paths<true, true, false>), g, b, lds, st, a);
-    else if (small && mis) hipLaunchKernelGGL((k_paths<true, true, true>), g, b, lds, st, a);
-    else if (small && !ovf) hipLaunchKernelGGL((k_paths<true, false, false>), g, b, lds, st, a);
-    else if (small) hipLaunchKernelGGL((k_paths<true, false, true>), g, b, lds, st, a);
-    else if (mis && !ovf) hipLaunchKernelGGL((k_paths<false, true, false>), g, b, lds, st, a);
-    else if (mis) hipLaunchKernelGGL((k_paths<false, true, true>), g, b, lds, st, a);
-    else if (!ovf) hipLaunchKernelGGL((k_paths<false, false, false>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_paths<false, false, true>), g, b, lds, st, a);
+    const int mode = scene_mode(a.sc, a.accel);
+    const size_t lds = scene_lds_bytes(a.sc, mode);
+    if (mode == kModeLds) launch_paths_mode<kModeLds>(a, grid, lds, st);
+    else if (mode == kModeTiled) launch_paths_mode<kModeTiled>(a, grid, lds, st);
+    else launch_paths_mode<kModeBvh>(a, grid, lds, st);
 }
 }  // namespace ptk
 namespace PTK_IMPL {
@@ -563,11 +689,11 @@ void launch_resolve(const ResolveArgs& a, hipStream_t st) {
 namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ debug: hit_scene on arbitrary rays
-template <bool SMALL>
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float* __restrict__ rays6, uint32_t n,
                                                       float t_min, float t_max, int32_t* out_id, float* out_t) {
     extern __shared__ float4 lds[];
-    const SceneRef sc = stage_scene<SMALL>(scv, lds);
+    const SceneRef sc = stage_scene<MODE>(scv, lds);
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
         bool active = i < n;
@@ -577,25 +703,27 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float
             d = normalize(mk(rays6[6 * (size_t)i + 3], rays6[6 * (size_t)i + 4], rays6[6 * (size_t)i + 5]));
         }
         int id; float t;
-        scan_closest<SMALL>(sc, o, d, t_min, t_max, id, t);
+        if (MODE == kModeBvh) bvh_scan<false>(sc, active, o, d, t_min, t_max, id, t);
+        else scan_closest<MODE>(sc, o, d, t_min, t_max, id, t);
         if (active) { out_id[i] = id; out_t[i] = id >= 0 ? t : 0.0f; }
     }
 }
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
-void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, const float* rays6, uint32_t n, float t_min, float t_max,
-                                 int32_t* out_id, float* out_t, hipStream_t st) {
-    const bool small = sc.n_objs <= kSmallObjs;
+void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min,
+                                 float t_max, int32_t* out_id, float* out_t, hipStream_t st) {
+    const int mode = scene_mode(sc, accel);
+    const size_t lds = scene_lds_bytes(sc, mode);
     uint32_t grid = (n + kBlock - 1) / kBlock;
     if (grid > 2048u) grid = 2048u;
     if (grid == 0u) grid = 1u;
-    if (small)
-        hipLaunchKernelGGL(k_debug_hit<true>, dim3(grid), dim3(kBlock), scene_lds_bytes(sc), st, sc, rays6, n, t_min,
-                           t_max, out_id, out_t);
+    if (mode == kModeLds)
+        hipLaunchKernelGGL(k_debug_hit<kModeLds>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
+    else if (mode == kModeTiled)
+        hipLaunchKernelGGL(k_debug_hit<kModeTiled>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
     else
-        hipLaunchKernelGGL(k_debug_hit<false>, dim3(grid), dim3(kBlock), scene_lds_bytes(sc), st, sc, rays6, n, t_min,
-                           t_max, out_id, out_t);
+        hipLaunchKernelGGL(k_debug_hit<kModeBvh>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
 }
 
 }  // namespace ptk
