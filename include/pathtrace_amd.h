@@ -214,6 +214,13 @@ int pt_debug_hit_scene(PtContext* ctx, const double* rays, uint32_t n,
                        double t_min, double t_max, uint32_t exact_math, uint32_t accel,
                        int32_t* out_id, float* out_t);
 
+/* Debug entry, host only (no GPU needed): build the accel = 1 BVH of a scene and verify it -- every object in
+ * exactly one leaf slot with its scan record, every child box encloses the boxes beneath it, depth within the
+ * traversal stack.  Returns PT_OK and the tree's size, or PT_ERR_UNSUPPORTED with the violated invariant in
+ * pt_last_error().  Any of the three outputs may be NULL.                                                    */
+int pt_debug_bvh_check(const PtObject* objs, uint32_t n_objs, uint32_t* depth, uint32_t* n_nodes,
+                       uint32_t* n_leaf_slots);
+
 const char* pt_last_error(void);
 uint32_t pt_abi_version(void);
 

@@ -95,6 +95,7 @@ SYMBOLS = {
     "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double, C.c_uint32,
                                      C.c_uint32, _P(C.c_int32), _P(C.c_float)]),
+    "pt_debug_bvh_check": (C.c_int, [_P(PtObject), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
     "pt_last_error": (C.c_char_p, []),
     "pt_abi_version": (C.c_uint32, []),
 }

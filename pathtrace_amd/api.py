@@ -151,6 +151,13 @@ class Context:
         return ids, ts
 
 
+def bvh_check(objs):
+    """pt_debug_bvh_check (host only): build + verify the accel = 1 BVH; returns (depth, nodes, leaf slots)."""
+    d, nn, nl = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    check(lib().pt_debug_bvh_check(objs, len(objs), C.byref(d), C.byref(nn), C.byref(nl)))
+    return d.value, nn.value, nl.value
+
+
 def render_host(cam, objs, params):
     """pt_render: the one-shot host-buffer entry (= src/main.rs:43-60)."""
     rows = tile_rows(cam.height, params.band_rows, params.band_index, params.band_count or 1)

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -91,6 +92,7 @@ struct PtContext {
     uint32_t bvh_depth = 0;
     // wavefront state
     DevBuf<float4> queue[4];
+    DevBuf<float4> bvh_aux, bvh_sray[2];   // accel = 1: per-slot scratch of the staged passes (k_paths_bvh)
     DevBuf<float4> ovf[2][4];         // overflow queues of the tail hand-off (ping-pong between launches)
     DevBuf<uint32_t> ovf_count;       // [2]
     uint32_t* h_ovf = nullptr;        // pinned read-back of one counter
@@ -133,12 +135,35 @@ std::vector<uint32_t> tile_row_list(uint32_t height, uint32_t band_rows, uint32_
 
 float4 f4(double a, double b, double c, double d) { return make_float4((float)a, (float)b, (float)c, (float)d); }
 
+// Shape records of one object: gather form (3 float4, pt_device.h) and scan records (1 float4 for a sphere, 3 for a triangle)
+void shape_records(const PtObject& o, float4 gather[3], float4 scan[3], int* n_scan) {
+    if (o.shape_tag == PT_SHAPE_SPHERE) {
+        float4 s = f4(o.shape[0], o.shape[1], o.shape[2], o.shape[3]);
+        gather[0] = s;
+        gather[1] = make_float4(1.0f / s.w, 0, 0, 0);       // 1/radius (shape.rs:86)
+        gather[2] = make_float4(0, 0, 0, 0);
+        s.w = s.w * s.w;                                     // scan record carries r^2 (shape.rs:63)
+        scan[0] = s;
+        *n_scan = 1;
+    } else {
+        float v0[3], v1[3], v2[3];
+        for (int k = 0; k < 3; ++k) { v0[k] = (float)o.shape[k]; v1[k] = (float)o.shape[3 + k]; v2[k] = (float)o.shape[6 + k]; }
+        gather[0] = make_float4(v0[0], v0[1], v0[2], 0.f);
+        gather[1] = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f);   // edge1, shape.rs:163
+        gather[2] = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f);   // edge2, shape.rs:164
+        scan[0] = gather[0]; scan[1] = gather[1]; scan[2] = gather[2];
+        *n_scan = 3;
+    }
+}
+
 // Build and upload the BVH of the uploaded scene (once per scene).
 int ensure_bvh(PtContext* c) {
     if (c->has_bvh) return PT_OK;
     if (c->view.n_objs >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "accel: %u objects exceed the 2^28 leaf slots", c->view.n_objs);
     ptbvh::Built b = ptbvh::build(c->h_shape.data(), c->h_shape_tag.data(), c->view.n_objs);
     static_assert(ptbvh::kStackDepth == ptk::kBvhStack, "traversal stack depth");
+    if (b.non_finite) return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate; the linear scan's answer for them "
+                                  "depends on the scan order, use accel = 0", b.non_finite);
     if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
     int rc;
     if ((rc = c->bvh_nodes.ensure(b.nodes.size() + 4)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
@@ -216,6 +241,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipStreamSynchronize(c->stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release();
+    c->bvh_aux.release(); c->bvh_sray[0].release(); c->bvh_sray[1].release();
     for (auto& b : c->queue) b.release();
     for (auto& q : c->ovf) for (auto& b : q) b.release();
     c->ovf_count.release();
@@ -253,21 +279,11 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
             runs.push_back(r);
         }
         runs.back().count++;
-        if (o.shape_tag == PT_SHAPE_SPHERE) {
-            float4 s = f4(o.shape[0], o.shape[1], o.shape[2], o.shape[3]);
-            shape[3 * i] = s;
-            shape[3 * i + 1] = make_float4(1.0f / s.w, 0, 0, 0);       // 1/radius (shape.rs:86)
-            shape[3 * i + 2] = make_float4(0, 0, 0, 0);
-            s.w = s.w * s.w;                                           // scan record carries r^2 (shape.rs:63)
-            scan.push_back(s);
-        } else {
-            float v0[3], v1[3], v2[3];
-            for (int k = 0; k < 3; ++k) { v0[k] = (float)o.shape[k]; v1[k] = (float)o.shape[3 + k]; v2[k] = (float)o.shape[6 + k]; }
-            float4 a0 = make_float4(v0[0], v0[1], v0[2], 0.f);
-            float4 a1 = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f);   // edge1, shape.rs:163
-            float4 a2 = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f);   // edge2, shape.rs:164
-            scan.push_back(a0); scan.push_back(a1); scan.push_back(a2);
-            shape[3 * i] = a0; shape[3 * i + 1] = a1; shape[3 * i + 2] = a2;
+        {
+            float4 sc3[3];
+            int ns = 0;
+            shape_records(o, &shape[3 * (size_t)i], sc3, &ns);
+            scan.insert(scan.end(), sc3, sc3 + ns);
         }
         float p[6] = {(float)o.mat[0], (float)o.mat[1], (float)o.mat[2], (float)o.mat[3], (float)o.mat[4], (float)o.mat[5]};
         uint32_t emits = 0;
@@ -387,6 +403,9 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
     for (int k = 0; k < 4; ++k)
         if ((rc = c->queue[k].ensure(q_slots))) return rc;
+    if (prm->accel && ((rc = c->bvh_aux.ensure(q_slots)) || (rc = c->bvh_sray[0].ensure(q_slots)) ||
+                       (rc = c->bvh_sray[1].ensure(q_slots))))
+        return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if ((rc = c->ovf_count.ensure(2))) return rc;
     if (hand_off)
@@ -399,6 +418,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     ptk::BounceArgs a{};
     for (int k = 0; k < 4; ++k) a.q.q[k] = c->queue[k].p;
     a.seg_cap = seg_cap;
+    a.aux = c->bvh_aux.p; a.sray0 = c->bvh_sray[0].p; a.sray1 = c->bvh_sray[1].p;
     a.lsamp = c->lsamp.p;
     a.stats = c->dstats.p;
     {   // tile row -> image row without a table (ptk::TileMap)
@@ -419,6 +439,11 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     a.t_min = (float)prm->t_min;
     a.integrator = prm->integrator;
     a.accel = prm->accel;
+    a.bvh_refill = ptk::kRefillBelow; a.bvh_leaf = ptk::kLeafBatch;
+    if (const char* e = std::getenv("PT_BVH_REFILL")) a.bvh_refill = (uint32_t)std::atoi(e);     // tuning knobs, results do not depend on them
+    if (const char* e = std::getenv("PT_BVH_LEAF")) a.bvh_leaf = (uint32_t)std::atoi(e);
+    if (a.bvh_refill < 1u) a.bvh_refill = 1u;
+    if (a.bvh_refill > 64u) a.bvh_refill = 64u;
 
     const bool profile = prm->profile != 0;
     HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
@@ -539,16 +564,106 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
     for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];
     DevBuf<float> d_r, d_t;
     DevBuf<int32_t> d_id;
-    struct Release { DevBuf<float>&a, &b; DevBuf<int32_t>& c; ~Release() { a.release(); b.release(); c.release(); } } guard{d_r, d_t, d_id};
+    DevBuf<float4> d_scratch;
+    struct Release { DevBuf<float>&a, &b; DevBuf<int32_t>& c; DevBuf<float4>& d; ~Release() { a.release(); b.release(); c.release(); d.release(); } }
+        guard{d_r, d_t, d_id, d_scratch};
     int rc;
     if ((rc = d_r.ensure(r6.size())) || (rc = d_id.ensure(n)) || (rc = d_t.ensure(n))) return rc;
+    if (accel && (rc = d_scratch.ensure(3 * (size_t)n))) return rc;
     HIP_TRY(hipMemcpy(d_r.p, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (exact_math) ptk::launch_debug_hit_exact(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
-    else ptk::launch_debug_hit_fast(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_id.p, d_t.p, c->stream);
+    if (exact_math) ptk::launch_debug_hit_exact(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, c->stream);
+    else ptk::launch_debug_hit_fast(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_id, d_id.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32_t* n_nodes, uint32_t* n_leaf_slots) {
+    if (!objs && n) return fail(PT_ERR_INVALID_ARG, "pt_debug_bvh_check: null objects");
+    if (n >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "accel: %u objects exceed the 2^28 leaf slots", n);
+    std::vector<float4> shape(3 * (size_t)n + 1), scan(3 * (size_t)n + 1);
+    std::vector<uint32_t> tag(n + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (objs[i].shape_tag > PT_SHAPE_TRIANGLE) return fail(PT_ERR_INVALID_ARG, "object %u: bad shape_tag %u", i, objs[i].shape_tag);
+        int ns = 0;
+        shape_records(objs[i], &shape[3 * (size_t)i], &scan[3 * (size_t)i], &ns);
+        tag[i] = objs[i].shape_tag;
+    }
+    const ptbvh::Built b = ptbvh::build(shape.data(), tag.data(), n);
+    if (depth) *depth = b.depth;
+    if (n_nodes) *n_nodes = (uint32_t)(b.nodes.size() / 4);
+    if (n_leaf_slots) *n_leaf_slots = (uint32_t)b.leaf_ids.size();
+    if (b.non_finite) return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate", b.non_finite);
+    if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", b.depth);
+    if (b.leaf_ids.size() != n || b.leaf_rec.size() != 3 * (size_t)n) return fail(PT_ERR_UNSUPPORTED, "%zu leaf slots for %u objects", b.leaf_ids.size(), n);
+    if (n == 0) return b.root == ptbvh::kDone ? PT_OK : fail(PT_ERR_UNSUPPORTED, "empty scene: root is not the sentinel");
+    // boxes of the primitives in f64 from the same f32 records the device tests
+    auto prim_box = [&](uint32_t o, double lo[3], double hi[3]) {
+        const float4 r0 = shape[3 * (size_t)o], r1 = shape[3 * (size_t)o + 1], r2 = shape[3 * (size_t)o + 2];
+        if (tag[o] == PT_SHAPE_SPHERE) {
+            const double r = std::sqrt((double)(r0.w * r0.w));
+            const double c[3] = {r0.x, r0.y, r0.z};
+            for (int k = 0; k < 3; ++k) { lo[k] = c[k] - r; hi[k] = c[k] + r; }
+        } else {
+            const double v0[3] = {r0.x, r0.y, r0.z}, e1[3] = {r1.x, r1.y, r1.z}, e2[3] = {r2.x, r2.y, r2.z};
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(v0[k], std::min(v0[k] + e1[k], v0[k] + e2[k]));
+                hi[k] = std::max(v0[k], std::max(v0[k] + e1[k], v0[k] + e2[k]));
+            }
+        }
+    };
+    std::vector<uint8_t> seen(n, 0);
+    std::string err;
+    // returns the exact bounds of the subtree; checks them against the box the parent stores for it
+    struct Walker {
+        const ptbvh::Built& b; const std::vector<float4>& scan; const std::vector<uint32_t>& tag; std::vector<uint8_t>& seen;
+        decltype(prim_box)& pbox; std::string& err; uint32_t n; uint32_t max_depth = 0;
+        bool walk(uint32_t code, uint32_t d, double lo[3], double hi[3]) {
+            for (int k = 0; k < 3; ++k) { lo[k] = 1e300; hi[k] = -1e300; }
+            if (d > max_depth) max_depth = d;
+            if (code == ptbvh::kDone) { err = "sentinel inside the tree"; return false; }
+            if (code & ptbvh::kLeafBit) {
+                const uint32_t first = code & 0x0FFFFFFFu, cnt = ((code >> 28) & 7u) + 1u;
+                if (cnt > ptbvh::kMaxLeaf || (size_t)first + cnt > b.leaf_ids.size()) { err = "leaf range out of bounds"; return false; }
+                for (uint32_t i = first; i < first + cnt; ++i) {
+                    const uint32_t w = b.leaf_ids[i], o = w & 0x7FFFFFFFu;
+                    if (o >= n || seen[o]) { err = "object missing or in two leaves"; return false; }
+                    seen[o] = 1;
+                    if (((w >> 31) != 0) != (tag[o] == PT_SHAPE_TRIANGLE)) { err = "leaf tag bit differs from the object's shape"; return false; }
+                    const int ns = tag[o] == PT_SHAPE_TRIANGLE ? 3 : 1;
+                    if (std::memcmp(&b.leaf_rec[3 * (size_t)i], &scan[3 * (size_t)o], ns * sizeof(float4)) != 0) { err = "leaf record differs from the scan record"; return false; }
+                    double pl[3], ph[3];
+                    pbox(o, pl, ph);
+                    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], pl[k]); hi[k] = std::max(hi[k], ph[k]); }
+                }
+                return true;
+            }
+            if (4 * (size_t)code + 3 >= b.nodes.size()) { err = "node index out of bounds"; return false; }
+            const float4 n0 = b.nodes[4 * (size_t)code], n1 = b.nodes[4 * (size_t)code + 1], n2 = b.nodes[4 * (size_t)code + 2],
+                         n3 = b.nodes[4 * (size_t)code + 3];
+            const float blo[2][3] = {{n0.x, n0.y, n0.z}, {n1.z, n1.w, n2.x}}, bhi[2][3] = {{n0.w, n1.x, n1.y}, {n2.y, n2.z, n2.w}};
+            uint32_t cc[2];
+            std::memcpy(&cc[0], &n3.x, 4); std::memcpy(&cc[1], &n3.y, 4);
+            for (int c = 0; c < 2; ++c) {
+                double cl[3], ch[3];
+                if (!walk(cc[c], d + 1, cl, ch)) return false;
+                for (int k = 0; k < 3; ++k) {
+                    if (!((double)blo[c][k] <= cl[k] && (double)bhi[c][k] >= ch[k])) { err = "child box does not enclose its subtree"; return false; }
+                    lo[k] = std::min(lo[k], cl[k]); hi[k] = std::max(hi[k], ch[k]);
+                }
+            }
+            return true;
+        }
+    } w{b, scan, tag, seen, prim_box, err, n};
+    double lo[3], hi[3];
+    if (!w.walk(b.root, 0, lo, hi)) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: %s", err.c_str());
+    for (uint32_t i = 0; i < n; ++i) if (!seen[i]) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: object %u is in no leaf", i);
+    if (w.max_depth != b.depth) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: depth %u reported, %u found", b.depth, w.max_depth);
+    double amax = 0.0;
+    for (int k = 0; k < 3; ++k) amax += std::max(std::fabs(lo[k]), std::fabs(hi[k]));
+    if (!((double)b.scene_abs >= amax)) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: scene_abs %g below the scene extent %g", (double)b.scene_abs, amax);
     return PT_OK;
 }
 

@@ -158,9 +158,12 @@ Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n) {
                 p.box.hi[k] = up(std::max(a, std::max(bq, c)));
             }
         }
+        bool finite = true;
+        for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(p.box.lo[k]) && std::isfinite(p.box.hi[k]);
+        if (!finite) b.out.non_finite++;
         for (int k = 0; k < 3; ++k) {
-            // a non-finite box (NaN/inf object) would poison every ancestor: make it cover everything instead
-            if (!(std::isfinite(p.box.lo[k]) && std::isfinite(p.box.hi[k]))) {
+            // a non-finite box would poison every ancestor: make it cover everything (the caller refuses the scene anyway)
+            if (!finite) {
                 p.box.lo[k] = -std::numeric_limits<float>::max(); p.box.hi[k] = std::numeric_limits<float>::max();
                 p.cen[k] = 0.f;
             } else {

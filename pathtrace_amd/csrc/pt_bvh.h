@@ -30,6 +30,10 @@ struct Built {
     uint32_t root = kDone;            // child code of the root
     uint32_t depth = 0;               // deepest leaf (root = 0)
     float scene_abs = 0.0f;           // sum over axes of the largest |coordinate| of any box: scale of the traversal padding
+    // Objects with a NaN/inf coordinate or radius.  The linear scan's answer for such an object depends on the
+    // scan order (a NaN t is "accepted" and then lets every later hit through, world.rs:281-287), which no
+    // traversal order reproduces: callers refuse accel = 1 for such scenes.
+    uint32_t non_finite = 0;
 };
 
 // shape: 3 float4 per object in the gather form of pt_device.h (sphere: (c, r), (1/r,..), -; triangle: v0, e1, e2);

@@ -71,6 +71,10 @@ struct BounceArgs {
     uint32_t src_mode;        // 0: pass 0 generates camera rays, 1: pass 0 reads ovf_in
     uint32_t export_below;    // >= 1; 1 = never export (a wave runs until its segment is empty)
     uint32_t seg_cap;         // slots per segment (multiple of 64)
+    // accel = 1 only (k_paths_bvh): per-slot scratch of the staged passes, same indexing as q
+    float4* aux;              // (closest-hit id, t, occluded, -)
+    float4* sray0;            // shadow ray (o, d.x)
+    float4* sray1;            // (d.y, d.z, t_max or -1 = none, -)
     float4* lsamp;            // per-path final radiance, index = s_local*np + tile_row*width + x
     unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)  [3] vertices of level-0 launches
     TileMap tile;
@@ -82,6 +86,7 @@ struct BounceArgs {
     uint32_t min_depth, max_depth;
     float t_min;
     uint32_t integrator;
+    uint32_t bvh_refill, bvh_leaf;   // traverse_segment thresholds (lanes)
     uint32_t accel;           // 0: linear scan (the reference's hit_scene), 1: BVH traversal, same answers
 };
 
@@ -91,6 +96,8 @@ constexpr uint32_t kBlock = 256;
 // through one LDS tile and gather shape/material records from global memory.
 constexpr uint32_t kSmallObjs = 128;
 constexpr uint32_t kTileF4 = 2550;         // 39.8 KiB LDS tile (divisible by 3: whole triangles); 4 workgroups per CU
+constexpr uint32_t kRefillBelow = 36;      // BVH traversal: hand out new rays when fewer lanes than this are tracing
+constexpr uint32_t kLeafBatch = 24;        // BVH traversal: test leaf primitives when at least this many lanes wait at a leaf
 constexpr uint32_t kBvhStack = 32;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 32 KiB per workgroup
 
 // One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
@@ -116,9 +123,10 @@ struct ResolveArgs {
 void launch_resolve(const ResolveArgs& a, hipStream_t st);
 
 // World::hit_scene on arbitrary rays (debug/parity entry).
+// scratch: accel = 1 only, 3*n float4 of device memory
 void launch_debug_hit_exact(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min, float t_max,
-                            int32_t* out_id, float* out_t, hipStream_t st);
+                            float4* scratch, int32_t* out_id, float* out_t, hipStream_t st);
 void launch_debug_hit_fast(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min, float t_max,
-                           int32_t* out_id, float* out_t, hipStream_t st);
+                           float4* scratch, int32_t* out_id, float* out_t, hipStream_t st);
 
 }  // namespace ptk

@@ -162,91 +162,16 @@ PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
     return r;
 }
 
-// hit_scene by BVH traversal.  Every primitive whose test the linear scan would have accepted is still
-// tested: a subtree is skipped only if the ray misses its box, enlarged by `pad` on every side, inside
-// [t_min, closest].  pad = 2^-15 (|o|_1 + scene extent) is ~100x the rounding error of the primitive tests
-// (their error scales with the distance between ray origin and primitive), so a hit that exists only through
-// rounding (a grazing ray) is inside the padded box as well.  Rays with a non-finite coordinate or a zero
-// direction (the reference lets NaN through its sphere test, Q10) take the linear scan, from global memory.
-// ANY: visibility query -- only "is there a hit" is used, so the lane stops at its first accepted primitive.
+// hit_scene by BVH traversal (traverse_segment below).  Every primitive whose test the linear scan would have
+// accepted is still tested: a subtree is skipped only if the ray misses its box, enlarged by `pad` on every
+// side, inside [t_min, closest].  pad = 2^-15 (|o|_1 + scene extent) is ~100x the rounding error of the
+// primitive tests (their error scales with the distance between ray origin and primitive), so a hit that exists
+// only through rounding (a grazing ray) is inside the padded box as well.  Rays with a non-finite coordinate or
+// a zero direction (the reference lets NaN through its sphere test, Q10) take the linear scan, from global
+// memory (scan_global).  A visibility query only uses "is there a hit": the lane stops at its first accepted
+// primitive.
 constexpr float kBvhPad = 1.0f / 32768.0f;
 PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out);
-template <bool ANY>
-PT_DEV void bvh_scan(const SceneRef& sc, bool active, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
-    const float a = dot(d, d);
-    const float inv_a = pt_rcp(a);
-    float closest = t_max;
-    int id = -1;
-    const float o1 = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
-    // a regular ray: finite coordinates and 0 < |d|^2 with a finite reciprocal (false for NaN).  normalize() leaves
-    // a zero vector as it is, and a zero direction makes every sphere test NaN (0 * inf) -- the scan's business.
-    const bool finite = o1 + __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) + a + inv_a < kInf;
-    if (active && finite) {
-        const float pad = kBvhPad * (o1 + sc.bvh.scene_abs);
-        const f3 op = mk(o.x + pad, o.y + pad, o.z + pad), om = mk(o.x - pad, o.y - pad, o.z - pad);
-        const f3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // +-inf for a zero component
-        uint32_t* stk = sc.stack + threadIdx.x;
-        stk[0] = 0xFFFFFFFFu;                  // ptbvh::kDone
-        uint32_t sp = 1;
-        uint32_t node = sc.bvh.root;
-        while (node != 0xFFFFFFFFu) {
-            while ((int)node >= 0) {           // internal node: test both child boxes
-                const float4* n = sc.bvh.nodes + 4u * node;
-                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                // slab test; min/max drop the NaN of 0 * inf (ray parallel to a slab, origin on its plane)
-                float ax0 = (n0.x - op.x) * inv.x, ax1 = (n0.w - om.x) * inv.x;
-                float ay0 = (n0.y - op.y) * inv.y, ay1 = (n1.x - om.y) * inv.y;
-                float az0 = (n0.z - op.z) * inv.z, az1 = (n1.y - om.z) * inv.z;
-                const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
-                const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
-                ax0 = (n1.z - op.x) * inv.x; ax1 = (n2.y - om.x) * inv.x;
-                ay0 = (n1.w - op.y) * inv.y; ay1 = (n2.z - om.y) * inv.y;
-                az0 = (n2.x - op.z) * inv.z; az1 = (n2.w - om.z) * inv.z;
-                const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
-                const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
-                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
-                if (h0 && h1) {
-                    const bool swap = tn1 < tn0;               // nearer child first
-                    stk[sp * kBlock] = swap ? c0 : c1;
-                    ++sp;
-                    node = swap ? c1 : c0;
-                } else if (h0 || h1) {
-                    node = h0 ? c0 : c1;
-                } else {
-                    --sp;
-                    node = stk[sp * kBlock];
-                }
-            }
-            if (node == 0xFFFFFFFFu) break;
-            const uint32_t first = node & 0x0FFFFFFFu, cnt = ((node >> 28) & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint32_t w = sc.bvh.ids[first + i];
-                const float4* rec = sc.bvh.rec + 3u * (first + i);
-                const float4 r0 = rec[0];
-                if ((int)w >= 0) {
-                    sphere_test<true>(r0, o, d, a, inv_a, t_min, closest, id, (int)w);
-                } else {
-                    const float4 r1 = rec[1], r2 = rec[2];
-                    triangle_test<true>(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), o, d, t_min, closest, id,
-                                        (int)(w & 0x7FFFFFFFu));
-                }
-            }
-            if (ANY && id >= 0) break;
-            --sp;
-            node = stk[sp * kBlock];
-        }
-    }
-    if (__ballot(active && !finite) != 0ull) {
-        if (active && !finite) scan_global(sc, o, d, t_min, t_max, id, closest);
-    }
-    id_out = id;
-    t_out = closest;
-}
 
 // World::hit_scene (world.rs:270-290): linear scan in object order with a
 // shrinking t_max.  kModeLds: the whole scan array already sits in LDS.  kModeTiled:
@@ -308,6 +233,157 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
     return q * t.band_stride + t.band_first + (yl - q * t.band_rows);
 }
 
+// ------------------------------------------------------------------ one path vertex
+// The per-vertex body of MisStrategy::ray_color / BrdfOnlyStrategy::ray_color (rendering.rs:34-142,
+// 214-265), cut at the visibility scan: vertex_begin (hit record, emitter credit, light sample) -> shadow
+// scan -> vertex_end (NEE term, BSDF sample, roulette, next ray).
+struct PathState {
+    f3 o, d, beta, L;
+    float pdf_prev, eta_in;
+    uint32_t s_local, depth, px, yl;
+};
+struct Vertex {
+    Hit hit;
+    Mat m;
+    bool alive;              // the path continues past this vertex (so far)
+    bool need_shadow;        // a light point was sampled: visibility of light_dir up to distance is needed
+    f3 light_dir, ls_emission;
+    float distance, ls_pdf;
+};
+
+PT_DEV PathState unpack_state(float4 q0, float4 q1, float4 q2, float4 q3) {
+    PathState p;
+    p.o = mk(q0.x, q0.y, q0.z); p.d = mk(q0.w, q1.x, q1.y);
+    p.beta = mk(q1.z, q1.w, q2.x); p.L = mk(q2.y, q2.z, q2.w);
+    p.pdf_prev = q3.x; p.eta_in = q3.y;
+    const uint32_t xy = __float_as_uint(q3.z), sd = __float_as_uint(q3.w);
+    p.yl = xy >> 16; p.px = xy & 0xFFFFu;
+    p.s_local = sd >> 16; p.depth = sd & 0xFFFFu;
+    return p;
+}
+PT_DEV void store_state(const Queue& q, uint32_t j, const PathState& p) {
+    q.q[0][j] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+    q.q[1][j] = make_float4(p.d.y, p.d.z, p.beta.x, p.beta.y);
+    q.q[2][j] = make_float4(p.beta.z, p.L.x, p.L.y, p.L.z);
+    q.q[3][j] = make_float4(p.pdf_prev, p.eta_in, __uint_as_float((p.yl << 16) | p.px),
+                            __uint_as_float((p.s_local << 16) | p.depth));
+}
+PT_DEV PathState parked_state() {
+    PathState p;
+    p.o = parked_origin(); p.d = parked_dir(); p.beta = mk(1.f, 1.f, 1.f); p.L = mk(0.f, 0.f, 0.f);
+    p.pdf_prev = 0.0f; p.eta_in = 1.0f;
+    p.s_local = 0; p.depth = 0; p.px = 0; p.yl = 0;
+    return p;
+}
+
+// Camera::get_ray_with_offset for sample `sample` of pixel (px, py) (camera.rs:139-147; jitter draws world.rs:299)
+PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_t py, f3& o, f3& d) {
+    uint32_t dc[4];
+    philox4x32_10(sample, kDepthCamera, 0u, 0u, px, py, dc);
+    float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
+    float u = pt_div((float)px + ox, (float)(cam.width - 1u));               // camera.rs:140
+    float v = pt_div((float)(cam.height - 1u - py) + oy, (float)(cam.height - 1u));   // world.rs:299 y flip
+    const f3 cam_o = mk(cam.origin[0], cam.origin[1], cam.origin[2]);
+    f3 dir = mk(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]) +
+             mk(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]) * u +
+             mk(cam.vertical[0], cam.vertical[1], cam.vertical[2]) * v - cam_o;   // camera.rs:143-144
+    o = cam_o;
+    d = normalize(dir);                                                   // Ray::new, camera.rs:13
+}
+
+// (id, t) = closest hit of the path ray, id < 0: miss.  Credits an emitter hit into p.L and samples the light point.
+template <bool MIS>
+PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, float t, uint32_t sample, uint32_t py,
+                         Vertex& v) {
+    v.alive = active && id >= 0;
+    v.hit.point = p.o; v.hit.normal = p.d; v.hit.t = 0.0f; v.hit.front_face = false;
+    v.m.tag = MAT_LAMBERT; v.m.shape_tag = 0; v.m.emits = 0; v.m.color = mk(0.f, 0.f, 0.f);
+    v.m.roughness = 0.f; v.m.metallic = 0.f; v.m.ior = 1.f; v.m.on_a = 1.f; v.m.on_b = 0.f;
+    if (v.alive) {
+        v.m = load_mat(sc.mat, id);
+        v.hit = finish_hit(sc.shape, id, v.m.shape_tag, p.o, p.d, t);
+        if (v.m.emits) {
+            if (!MIS || p.depth == 0u) {
+                p.L = p.L + p.beta * v.m.color;                                   // rendering.rs:44-45 / :225-227
+            } else {
+                // emitter reached by a BSDF-sampled ray: MIS weight against the light
+                // pdf seen from the previous vertex = this ray's origin (rendering.rs:107-121)
+                f3 sp; float pdf_shape;
+                shape_sample(sc.shape, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, pdf_shape);
+                float w_bsdf = pt_div(p.pdf_prev, p.pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
+                p.L = p.L + p.beta * v.m.color * w_bsdf;
+            }
+            v.alive = false;
+        }
+    }
+
+    // ---- NEE: light pick + surface sample (world.rs:251-267)
+    v.need_shadow = false;
+    v.light_dir = mk(0.f, 0.f, 0.f); v.ls_emission = mk(0.f, 0.f, 0.f);
+    v.distance = 0.0f; v.ls_pdf = 1.0f;
+    if (MIS && v.alive && sc.n_lights > 0u) {
+        uint32_t dl[4];
+        philox4x32_10(sample, p.depth, BLK_LIGHT, 0u, p.px, py, dl);
+        uint32_t li = __umulhi(dl[0], sc.n_lights);                           // random_range(0..n), world.rs:255
+        int lobj = (int)sc.lights[li];
+        Mat lm = load_mat(sc.mat, lobj);
+        f3 lp; float pdf_shape;
+        shape_sample(sc.shape, lobj, lm.shape_tag, v.hit.point, false, v.hit.point, u01(dl[1]), u01(dl[2]), lp,
+                     pdf_shape);
+        v.ls_emission = lm.color;                                             // world.rs:259
+        v.ls_pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);   // world.rs:260 (x/1 == x)
+        f3 to_light = lp - v.hit.point;                                       // rendering.rs:58-60
+        v.distance = length(to_light);
+        v.light_dir = normalize(to_light);
+        v.need_shadow = true;
+    }
+}
+
+// visible: the shadow scan found nothing between the vertex and the light point.  Returns "the path goes on";
+// p is then the state at the next vertex.
+template <bool MIS>
+PT_DEV bool vertex_end(PathState& p, const Vertex& v, bool visible, uint32_t sample, uint32_t py, uint32_t min_depth,
+                       uint32_t max_depth) {
+    f3 direct = mk(0.f, 0.f, 0.f);
+    if (MIS && visible) {
+        float cos_theta = __builtin_fabsf(dot(v.hit.normal, v.light_dir));    // rendering.rs:68
+        f3 bsdf; float pdf_bsdf;
+        bsdf_pdf(v.m, p.d, p.eta_in, v.light_dir, v.hit.normal, bsdf, pdf_bsdf);   // :71-72 (stale eta, Q5)
+        float w_nee = pt_div(v.ls_pdf, v.ls_pdf + pdf_bsdf);                       // :73
+        direct = w_nee * bsdf * v.ls_emission * cos_theta / v.ls_pdf;         // :75-76
+    }
+
+    // ---- BSDF sample, throughput, Russian roulette (rendering.rs:83-102)
+    bool alive = v.alive;
+    if (alive) {
+        uint32_t db[4];
+        philox4x32_10(sample, p.depth, BLK_BSDF, 0u, p.px, py, db);
+        float eta_mat = v.m.tag == MAT_MIRROR ? v.m.ior : 1.0f;               // get_eta, material.rs:50 / mirror.rs:317
+        float eta_here = v.hit.front_face ? pt_rcp(eta_mat) : eta_mat;         // rendering.rs:20-25
+        f3 wo, bsdf; float pdf, cos_theta;
+        bsdf_pdf_sample(v.m, p.d, eta_here, v.hit.normal, db, wo, bsdf, pdf, cos_theta);   // :84-85
+        f3 next_tp = p.beta * bsdf * cos_theta / pdf;                         // :89
+        float rr = rr_prob(p.depth, min_depth, max_depth, next_tp);           // :91-98
+        if (u01(db[3]) > rr) {                                                // :100-102 (drops direct, Q1)
+            alive = false;
+        } else {
+            p.L = p.L + p.beta * direct;
+            p.beta = rr == 1.0f ? next_tp : next_tp / rr;                     // :129 (x * (1/1) == x exactly)
+            if (is_zero(p.beta) || p.depth >= 65534u) {                       // Q7: nothing downstream contributes
+                alive = false;
+            } else {
+                p.pdf_prev = pdf;
+                p.o = v.hit.point;
+                p.d = v.m.tag == MAT_EMISSIVE ? normalize(wo) : wo;           // Ray::new, :86; every sampler but
+                                                                              // Emissive's returns a normalised wo
+                p.eta_in = eta_here;                                          // :87
+                p.depth += 1u;
+            }
+        }
+    }
+    return alive;
+}
+
 // ------------------------------------------------------------------ the path kernel
 // Queue organisation.  The path queue is cut into one PRIVATE segment per wave
 // (segment w = slots [w*seg_cap, (w+1)*seg_cap)).  A wave reads its segment 64
@@ -339,8 +415,9 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 template <int MODE, bool MIS, bool OVF>   // OVF: continuation launch, pass 0 reads the overflow queue
 __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a) {
     // SMALL = "the waves of a workgroup are independent" (no barrier inside the scan): wave-private queue
-    // segments.  Only the tiled scan ties the four waves of a workgroup together.
-    constexpr bool SMALL = MODE != kModeTiled;
+    // segments.  The tiled scan ties the four waves of a workgroup together.  (kModeBvh: k_paths_bvh.)
+    static_assert(MODE == kModeLds || MODE == kModeTiled, "linear-scan kernel");
+    constexpr bool SMALL = MODE == kModeLds;
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
     const SceneRef sc = stage_scene<MODE>(a.sc, lds);
@@ -354,7 +431,6 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     const uint32_t wib = threadIdx.x >> 6;                       // wave in block
     const uint32_t seg_base = SMALL ? wave * a.seg_cap : blockIdx.x * (kBlock / 64) * a.seg_cap;
     const uint32_t n_chunks = (a.n_first + 63u) >> 6;              // pass 0: 64-path chunks of the batch
-    const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
     const uint32_t W = a.cam.width;
     uint32_t n_in = 0;                     // wave-uniform: queued paths of this wave's segment
     uint32_t wave_shadow = 0, wave_vertices = 0;
@@ -379,9 +455,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
 
     for (uint32_t it = 0; it < n_iter; ++it) {
         bool active;
-        f3 o = parked_origin(), d = parked_dir(), beta = mk(1.f, 1.f, 1.f), L = mk(0.f, 0.f, 0.f);
-        float pdf_prev = 0.0f, eta_in = 1.0f;
-        uint32_t s_local = 0, depth = 0, px = 0, yl = 0, py = 0;
+        PathState p = parked_state();
 
         if (first) {
             const uint32_t chunk = it * nw + wave;
@@ -390,30 +464,18 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
             if (active) {
                 if (from_overflow) {
                     // continuation launch: the paths are the leftovers an earlier launch exported
-                    const float4 q0 = a.ovf_in.q[0][pid], q1 = a.ovf_in.q[1][pid], q2 = a.ovf_in.q[2][pid],
-                                 q3 = a.ovf_in.q[3][pid];
-                    o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y);
-                    beta = mk(q1.z, q1.w, q2.x); L = mk(q2.y, q2.z, q2.w);
-                    pdf_prev = q3.x; eta_in = q3.y;
-                    const uint32_t xy = __float_as_uint(q3.z), sd = __float_as_uint(q3.w);
-                    yl = xy >> 16; px = xy & 0xFFFFu;
-                    s_local = sd >> 16; depth = sd & 0xFFFFu;
+                    p = unpack_state(a.ovf_in.q[0][pid], a.ovf_in.q[1][pid], a.ovf_in.q[2][pid], a.ovf_in.q[3][pid]);
                 } else {
-                    s_local = pid / a.np;
-                    const uint32_t pix = pid - s_local * a.np;
-                    yl = pix / W;
-                    px = pix - yl * W;
+                    p.s_local = pid / a.np;
+                    const uint32_t pix = pid - p.s_local * a.np;
+                    p.yl = pix / W;
+                    p.px = pix - p.yl * W;
                 }
             }
         } else {
             active = it * chunk_slots + lane_off < n_in;
-            o = mk(n0.x, n0.y, n0.z); d = mk(n0.w, n1.x, n1.y);
-            beta = mk(n1.z, n1.w, n2.x); L = mk(n2.y, n2.z, n2.w);
-            pdf_prev = n3.x; eta_in = n3.y;
-            const uint32_t xy = __float_as_uint(n3.z), sd = __float_as_uint(n3.w);
-            yl = xy >> 16; px = xy & 0xFFFFu;
-            s_local = sd >> 16; depth = sd & 0xFFFFu;
-            if (!active) { o = parked_origin(); d = parked_dir(); }
+            p = unpack_state(n0, n1, n2, n3);
+            if (!active) { p.o = parked_origin(); p.d = parked_dir(); }
             // request the next chunk now; it is consumed just before this iteration's stores
             const uint32_t nxt = (it + 1u) * chunk_slots + lane_off;
             if (nxt < n_in) {
@@ -421,135 +483,44 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
                 n0 = a.q.q[0][s1]; n1 = a.q.q[1][s1]; n2 = a.q.q[2][s1]; n3 = a.q.q[3][s1];
             }
         }
-        py = image_row(a.tile, yl);                  // key of the path's RNG stream = (x, y), main.rs:51
-        const uint32_t sample = a.s_base + s_local;
+        const uint32_t py = image_row(a.tile, p.yl);     // key of the path's RNG stream = (x, y), main.rs:51
+        const uint32_t sample = a.s_base + p.s_local;
 
-        if (first && !from_overflow && active) {
-            uint32_t dc[4];
-            philox4x32_10(sample, kDepthCamera, 0u, 0u, px, py, dc);
-            float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
-            float u = pt_div((float)px + ox, (float)(a.cam.width - 1u));               // camera.rs:140
-            float v = pt_div((float)(a.cam.height - 1u - py) + oy, (float)(a.cam.height - 1u));   // world.rs:299 y flip
-            f3 dir = mk(a.cam.lower_left[0], a.cam.lower_left[1], a.cam.lower_left[2]) +
-                     mk(a.cam.horizontal[0], a.cam.horizontal[1], a.cam.horizontal[2]) * u +
-                     mk(a.cam.vertical[0], a.cam.vertical[1], a.cam.vertical[2]) * v - cam_o;   // camera.rs:143-144
-            o = cam_o;
-            d = normalize(dir);                                                   // Ray::new, camera.rs:13
-        }
+        if (first && !from_overflow && active) camera_ray(a.cam, sample, p.px, py, p.o, p.d);
 
         wave_vertices += (uint32_t)__popcll(__ballot(active));
         // deepest vertex: in a level-0 launch every path of pass p is at depth p; only a continuation launch
         // mixes depths inside a wave and has to look at the lanes
         if (!from_overflow) {
             wave_depth = pass;
-        } else if (__ballot(active && depth > wave_depth) != 0ull) {
-            uint32_t v = active ? depth : 0u;
+        } else if (__ballot(active && p.depth > wave_depth) != 0ull) {
+            uint32_t v = active ? p.depth : 0u;
             for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)v, off); v = w2 > v ? w2 : v; }
             wave_depth = __builtin_amdgcn_readfirstlane(v);
         }
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
-        if (MODE == kModeBvh) bvh_scan<false>(sc, active, o, d, a.t_min, kInf, id, t);
-        else scan_closest<MODE>(sc, o, d, a.t_min, kInf, id, t);
-        bool alive = active && id >= 0;
-
-        Hit hit;
-        Mat m;
-        hit.point = o; hit.normal = d; hit.t = 0.0f; hit.front_face = false;
-        m.tag = MAT_LAMBERT; m.shape_tag = 0; m.emits = 0; m.color = mk(0.f, 0.f, 0.f);
-        m.roughness = 0.f; m.metallic = 0.f; m.ior = 1.f; m.on_a = 1.f; m.on_b = 0.f;
-        if (alive) {
-            m = load_mat(sc.mat, id);
-            hit = finish_hit(sc.shape, id, m.shape_tag, o, d, t);
-            if (m.emits) {
-                if (!MIS || depth == 0u) {
-                    L = L + beta * m.color;                                       // rendering.rs:44-45 / :225-227
-                } else {
-                    // emitter reached by a BSDF-sampled ray: MIS weight against the light
-                    // pdf seen from the previous vertex = this ray's origin (rendering.rs:107-121)
-                    f3 sp; float pdf_shape;
-                    shape_sample(sc.shape, id, m.shape_tag, o, true, hit.point, 0.f, 0.f, sp, pdf_shape);
-                    float w_bsdf = pt_div(pdf_prev, pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
-                    L = L + beta * m.color * w_bsdf;
-                }
-                alive = false;
-            }
-        }
-
-        // ---- NEE: light pick + surface sample (world.rs:251-267)
-        bool need_shadow = false;
-        f3 light_dir = mk(0.f, 0.f, 0.f), ls_emission = mk(0.f, 0.f, 0.f);
-        float distance = 0.0f, ls_pdf = 1.0f;
-        if (MIS && alive && sc.n_lights > 0u) {
-            uint32_t dl[4];
-            philox4x32_10(sample, depth, BLK_LIGHT, 0u, px, py, dl);
-            uint32_t li = __umulhi(dl[0], sc.n_lights);                           // random_range(0..n), world.rs:255
-            int lobj = (int)sc.lights[li];
-            Mat lm = load_mat(sc.mat, lobj);
-            f3 lp; float pdf_shape;
-            shape_sample(sc.shape, lobj, lm.shape_tag, hit.point, false, hit.point, u01(dl[1]), u01(dl[2]), lp,
-                         pdf_shape);
-            ls_emission = lm.color;                                               // world.rs:259
-            ls_pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);   // world.rs:260 (x/1 == x)
-            f3 to_light = lp - hit.point;                                         // rendering.rs:58-60
-            distance = length(to_light);
-            light_dir = normalize(to_light);
-            need_shadow = true;
-        }
+        scan_closest<MODE>(sc, p.o, p.d, a.t_min, kInf, id, t);
+        Vertex v;
+        vertex_begin<MIS>(sc, p, active, id, t, sample, py, v);
 
         // ---- scan #2: visibility (rendering.rs:62-65); skipped when no lane needs it
         bool visible = false;
         if (MIS) {
-            bool any_shadow = SMALL ? (__ballot(need_shadow) != 0ull) : (__syncthreads_or(need_shadow) != 0);
+            bool any_shadow = SMALL ? (__ballot(v.need_shadow) != 0ull) : (__syncthreads_or(v.need_shadow) != 0);
             if (any_shadow) {
                 // Ray::new (rendering.rs:62) would normalise light_dir a second time; the f32
                 // arithmetic specification normalises a direction once
-                f3 sdir = need_shadow ? light_dir : parked_dir();
-                f3 sorg = need_shadow ? hit.point : parked_origin();
+                f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
+                f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                 int sid; float st;
-                if (MODE == kModeBvh) bvh_scan<true>(sc, need_shadow, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
-                else scan_closest<MODE>(sc, sorg, sdir, a.t_min, distance - a.t_min, sid, st);
-                visible = need_shadow && sid < 0;
-                wave_shadow += (uint32_t)__popcll(__ballot(need_shadow));
+                scan_closest<MODE>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                visible = v.need_shadow && sid < 0;
+                wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
         }
-        f3 direct = mk(0.f, 0.f, 0.f);
-        if (visible) {
-            float cos_theta = __builtin_fabsf(dot(hit.normal, light_dir));        // rendering.rs:68
-            f3 bsdf; float pdf_bsdf;
-            bsdf_pdf(m, d, eta_in, light_dir, hit.normal, bsdf, pdf_bsdf);        // :71-72 (stale eta, Q5)
-            float w_nee = pt_div(ls_pdf, ls_pdf + pdf_bsdf);                           // :73
-            direct = w_nee * bsdf * ls_emission * cos_theta / ls_pdf;             // :75-76
-        }
-
-        // ---- BSDF sample, throughput, Russian roulette (rendering.rs:83-102)
-        if (alive) {
-            uint32_t db[4];
-            philox4x32_10(sample, depth, BLK_BSDF, 0u, px, py, db);
-            float eta_mat = m.tag == MAT_MIRROR ? m.ior : 1.0f;                   // get_eta, material.rs:50 / mirror.rs:317
-            float eta_here = hit.front_face ? pt_rcp(eta_mat) : eta_mat;           // rendering.rs:20-25
-            f3 wo, bsdf; float pdf, cos_theta;
-            bsdf_pdf_sample(m, d, eta_here, hit.normal, db, wo, bsdf, pdf, cos_theta);   // :84-85
-            f3 next_tp = beta * bsdf * cos_theta / pdf;                           // :89
-            float rr = rr_prob(depth, a.min_depth, a.max_depth, next_tp);         // :91-98
-            if (u01(db[3]) > rr) {                                                // :100-102 (drops direct, Q1)
-                alive = false;
-            } else {
-                L = L + beta * direct;
-                beta = rr == 1.0f ? next_tp : next_tp / rr;                       // :129 (x * (1/1) == x exactly)
-                if (is_zero(beta) || depth >= 65534u) {                           // Q7: nothing downstream contributes
-                    alive = false;
-                } else {
-                    pdf_prev = pdf;
-                    o = hit.point;
-                    d = m.tag == MAT_EMISSIVE ? normalize(wo) : wo;               // Ray::new, :86; every sampler but
-                                                                                  // Emissive's returns a normalised wo
-                    eta_in = eta_here;                                            // :87
-                    depth += 1u;
-                }
-            }
-        }
+        const bool alive = vertex_end<MIS>(p, v, visible, sample, py, a.min_depth, a.max_depth);
 
         // ---- the next chunk must have landed before anything is stored (in-place queue)
         if (!first) {
@@ -560,7 +531,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
         }
 
         // ---- retire, or compact in place into the wave's own segment
-        if (active && !alive) a.lsamp[s_local * a.np + yl * W + px] = make_float4(L.x, L.y, L.z, 0.0f);
+        if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
         const unsigned long long mask = __ballot(alive);
         uint32_t cnt_before = 0, cnt_all = (uint32_t)__popcll(mask);
         if (!SMALL) {
@@ -571,14 +542,7 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
             cnt_all = 0;
             for (uint32_t k = 0; k < kBlock / 64; ++k) { cnt_before += k < wib ? s_iters[k] : 0u; cnt_all += s_iters[k]; }
         }
-        if (alive) {
-            const uint32_t j = seg_base + out_n + cnt_before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            a.q.q[0][j] = make_float4(o.x, o.y, o.z, d.x);
-            a.q.q[1][j] = make_float4(d.y, d.z, beta.x, beta.y);
-            a.q.q[2][j] = make_float4(beta.z, L.x, L.y, L.z);
-            a.q.q[3][j] = make_float4(pdf_prev, eta_in, __uint_as_float((yl << 16) | px),
-                                      __uint_as_float((s_local << 16) | depth));
-        }
+        if (alive) store_state(a.q, seg_base + out_n + cnt_before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
         out_n += cnt_all;
     }
     n_in = out_n;
@@ -619,6 +583,255 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
     }
 }
 
+// ------------------------------------------------------------------ the path kernel, BVH form
+// Same organisation as k_paths (one launch per batch, wave-private queue segments compacted in place, tail
+// hand-off), but a BVH traversal diverges: rays of one wave need between a handful and a few hundred steps,
+// and a wave that traces 64 rays side by side idles most lanes most of the time (measured on C4: 17 % of the
+// VALU lane-cycles did work).  So every pass over a segment is cut into stages, and the two traversal stages
+// hand a NEW ray to a lane as soon as its ray is done (traverse_segment):
+//     stage 1  extend   closest hit of every path ray of the segment          -> aux[slot].xy = (id, t)
+//     stage 2  connect  hit record + light sample of every path (vertex_begin) -> shadow ray of the slot
+//     stage 3  occlude  any-hit traversal of the shadow rays                   -> aux[slot].z
+//     stage 4  shade    vertex_begin again (cheaper than storing it) + vertex_end, in-place compaction
+// Pass 0 first writes the camera rays (or the overflow queue's paths) into the segment.
+
+// Rays of a segment: plane0[slot] = (o, d.x), plane1[slot] = (d.y, d.z, t_max if TMAX_IN_RAY, -); a negative
+// t_max marks a slot without a ray.  ANY: out[slot].z = 1 if anything is hit, else 0 (visibility).  Otherwise
+// out[slot].xy = (id, t) of the closest hit.  Semantics of one ray: bvh_scan.
+template <bool TMAX_IN_RAY, bool ANY>
+PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plane0, const float4* __restrict__ plane1,
+                             float4* __restrict__ out, uint32_t n, float t_min, uint32_t refill_below, uint32_t leaf_batch) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* stk = sc.stack + threadIdx.x;
+    uint32_t next = 0;                         // wave-uniform: first slot not handed out yet
+    bool has = false;                          // this lane is tracing a ray
+    uint32_t slot = 0, node = 0xFFFFFFFFu, sp = 1;
+    f3 o = parked_origin(), d = parked_dir(), inv = mk(0.f, 0.f, 0.f), op = o, om = o;
+    float a = 1.0f, inv_a = 1.0f, closest = 0.0f;
+    int id = -1;
+    for (;;) {
+        // ---- hand the next slots to the idle lanes, in lane order
+        const unsigned long long idle = __ballot(!has);
+        if (next < n && idle != 0ull) {
+            const uint32_t cand = next + (uint32_t)__popcll(idle & lt);
+            if (!has && cand < n) {
+                const float4 r0 = plane0[cand], r1 = plane1[cand];
+                const float t_max = TMAX_IN_RAY ? r1.z : kInf;
+                if (!TMAX_IN_RAY || t_max >= 0.0f) {
+                    slot = cand;
+                    o = mk(r0.x, r0.y, r0.z); d = mk(r0.w, r1.x, r1.y);
+                    a = dot(d, d);
+                    inv_a = pt_rcp(a);
+                    closest = t_max;
+                    id = -1;
+                    const float o1 = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
+                    const bool regular = o1 + __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) + a + inv_a < kInf;
+                    if (regular) {
+                        const float pad = kBvhPad * (o1 + sc.bvh.scene_abs);
+                        op = mk(o.x + pad, o.y + pad, o.z + pad); om = mk(o.x - pad, o.y - pad, o.z - pad);
+                        inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                        stk[0] = 0xFFFFFFFFu;
+                        sp = 1;
+                        node = sc.bvh.root;
+                    } else {
+                        scan_global(sc, o, d, t_min, t_max, id, closest);      // the linear scan's NaN behaviour (rare)
+                        node = 0xFFFFFFFFu;
+                    }
+                    has = true;
+                }
+            }
+            const uint32_t given = (uint32_t)__popcll(idle);
+            next = n - next < given ? n : next + given;
+        }
+        if (__ballot(has) == 0ull) {
+            if (next >= n) break;
+            continue;
+        }
+        const uint32_t low_water = next < n ? refill_below : 1u;
+        do {
+            if (has && (int)node >= 0) {                 // internal node: test both child boxes
+                const float4* nd = sc.bvh.nodes + 4u * node;
+                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                float ax0 = (n0.x - op.x) * inv.x, ax1 = (n0.w - om.x) * inv.x;
+                float ay0 = (n0.y - op.y) * inv.y, ay1 = (n1.x - om.y) * inv.y;
+                float az0 = (n0.z - op.z) * inv.z, az1 = (n1.y - om.z) * inv.z;
+                const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
+                const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
+                ax0 = (n1.z - op.x) * inv.x; ax1 = (n2.y - om.x) * inv.x;
+                ay0 = (n1.w - op.y) * inv.y; ay1 = (n2.z - om.y) * inv.y;
+                az0 = (n2.x - op.z) * inv.z; az1 = (n2.w - om.z) * inv.z;
+                const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
+                const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+                if (h0 && h1) {
+                    const bool swap = tn1 < tn0;               // nearer child first
+                    stk[sp * kBlock] = swap ? c0 : c1;
+                    ++sp;
+                    node = swap ? c1 : c0;
+                } else if (h0 || h1) {
+                    node = h0 ? c0 : c1;
+                } else {
+                    --sp;
+                    node = stk[sp * kBlock];
+                }
+            }
+            const bool at_leaf = has && (int)node < 0 && node != 0xFFFFFFFFu;
+            const unsigned long long leafs = __ballot(at_leaf);
+            if (leafs != 0ull && ((uint32_t)__popcll(leafs) >= leaf_batch || __ballot(has && (int)node >= 0) == 0ull)) {
+                if (at_leaf) {
+                    const uint32_t first = node & 0x0FFFFFFFu, cnt = ((node >> 28) & 7u) + 1u;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const uint32_t w = sc.bvh.ids[first + i];
+                        const float4* rec = sc.bvh.rec + 3u * (first + i);
+                        const float4 r0 = rec[0];
+                        if ((int)w >= 0) {
+                            sphere_test<true>(r0, o, d, a, inv_a, t_min, closest, id, (int)w);
+                        } else {
+                            const float4 r1 = rec[1], r2 = rec[2];
+                            triangle_test<true>(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), o, d, t_min,
+                                                closest, id, (int)(w & 0x7FFFFFFFu));
+                        }
+                    }
+                    if (ANY && id >= 0) {
+                        node = 0xFFFFFFFFu;
+                    } else {
+                        --sp;
+                        node = stk[sp * kBlock];
+                    }
+                }
+            }
+            if (has && node == 0xFFFFFFFFu) {            // this ray is done
+                if (ANY) out[slot].z = id >= 0 ? 1.0f : 0.0f;
+                else *reinterpret_cast<float2*>(&out[slot]) = make_float2(__int_as_float(id), closest);
+                has = false;
+            }
+        } while ((uint32_t)__popcll(__ballot(has)) >= low_water);
+    }
+}
+
+#ifndef PT_BVH_WAVES
+#define PT_BVH_WAVES 4
+#endif
+template <bool MIS, bool OVF>
+__global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a) {
+    extern __shared__ float4 lds[];
+    const SceneRef sc = stage_scene<kModeBvh>(a.sc, lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (kBlock / 64);
+    const uint32_t seg_base = wave * a.seg_cap;
+    const uint32_t n_chunks = (a.n_first + 63u) >> 6;
+    const uint32_t W = a.cam.width;
+    const Queue q = {{a.q.q[0] + seg_base, a.q.q[1] + seg_base, a.q.q[2] + seg_base, a.q.q[3] + seg_base}};
+    float4* const aux = a.aux + seg_base;
+    float4* const sr0 = a.sray0 + seg_base;
+    float4* const sr1 = a.sray1 + seg_base;
+    uint32_t wave_shadow = 0, wave_vertices = 0, wave_depth = 0;
+
+    // ---- the wave's share of the batch -> its segment (chunk k of the batch belongs to wave k % nw)
+    uint32_t n_in = 0;
+    for (uint32_t it = 0, n_iter = (n_chunks + nw - 1u) / nw; it < n_iter; ++it) {
+        const uint32_t chunk = it * nw + wave;
+        const uint32_t pid = chunk * 64u + lane;
+        const bool active = chunk < n_chunks && pid < a.n_first;
+        if (active) {
+            PathState p = parked_state();
+            if (OVF) {
+                p = unpack_state(a.ovf_in.q[0][pid], a.ovf_in.q[1][pid], a.ovf_in.q[2][pid], a.ovf_in.q[3][pid]);
+            } else {
+                p.s_local = pid / a.np;
+                const uint32_t pix = pid - p.s_local * a.np;
+                p.yl = pix / W;
+                p.px = pix - p.yl * W;
+                camera_ray(a.cam, a.s_base + p.s_local, p.px, image_row(a.tile, p.yl), p.o, p.d);
+            }
+            store_state(q, it * 64u + lane, p);     // dense: only the last chunk of the batch can be partial
+        }
+        n_in += (uint32_t)__popcll(__ballot(active));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+
+    for (uint32_t pass = 0; n_in != 0u; ++pass) {
+        const uint32_t n_iter = (n_in + 63u) >> 6;
+        // ---- stage 1: closest hits (rendering.rs:41)
+        traverse_segment<false, false>(sc, q.q[0], q.q[1], aux, n_in, a.t_min, a.bvh_refill, a.bvh_leaf);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (MIS) {
+            // ---- stage 2: light samples -> shadow rays (world.rs:251-267, rendering.rs:58-62)
+            for (uint32_t it = 0; it < n_iter; ++it) {
+                const uint32_t s = it * 64u + lane;
+                const bool active = s < n_in;
+                PathState p = parked_state();
+                float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+                if (active) { p = unpack_state(q.q[0][s], q.q[1][s], make_float4(0.f, 0.f, 0.f, 0.f), q.q[3][s]); h = aux[s]; }
+                Vertex v;
+                vertex_begin<true>(sc, p, active, __float_as_int(h.x), h.y, a.s_base + p.s_local, image_row(a.tile, p.yl), v);
+                if (active) {
+                    sr0[s] = make_float4(v.hit.point.x, v.hit.point.y, v.hit.point.z, v.light_dir.x);
+                    sr1[s] = make_float4(v.light_dir.y, v.light_dir.z, v.need_shadow ? v.distance - a.t_min : -1.0f, 0.f);
+                }
+                wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            // ---- stage 3: visibility (rendering.rs:62-65)
+            traverse_segment<true, true>(sc, sr0, sr1, aux, n_in, a.t_min, a.bvh_refill, a.bvh_leaf);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        }
+        // ---- stage 4: shade and compact in place
+        uint32_t out_n = 0;
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            const uint32_t s = it * 64u + lane;
+            const bool active = s < n_in;
+            PathState p = parked_state();
+            float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+            if (active) { p = unpack_state(q.q[0][s], q.q[1][s], q.q[2][s], q.q[3][s]); h = aux[s]; }
+            const uint32_t py = image_row(a.tile, p.yl);
+            const uint32_t sample = a.s_base + p.s_local;
+            wave_vertices += (uint32_t)__popcll(__ballot(active));
+            if (!OVF) {
+                wave_depth = pass;
+            } else if (__ballot(active && p.depth > wave_depth) != 0ull) {
+                uint32_t m = active ? p.depth : 0u;
+                for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)m, off); m = w2 > m ? w2 : m; }
+                wave_depth = __builtin_amdgcn_readfirstlane(m);
+            }
+            Vertex v;
+            vertex_begin<MIS>(sc, p, active, __float_as_int(h.x), h.y, sample, py, v);
+            const bool visible = MIS && v.need_shadow && h.z == 0.0f;
+            const bool alive = vertex_end<MIS>(p, v, visible, sample, py, a.min_depth, a.max_depth);
+            if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
+            const unsigned long long mask = __ballot(alive);
+            if (alive) store_state(q, out_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+            out_n += (uint32_t)__popcll(mask);
+        }
+        n_in = out_n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (n_in < a.export_below) break;
+    }
+
+    if (n_in != 0u) {                          // tail hand-off, as in k_paths
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(a.ovf_out_count, n_in);
+        base = __shfl(base, 0);
+        if (lane < n_in) {
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + lane]; a.ovf_out.q[k][base + lane] = t; }
+        }
+    }
+    if (lane == 0u) {
+        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
+        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
+        if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
+        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
+    }
+}
+
 static int scene_mode(const SceneView& sc, uint32_t accel) {
     return accel ? kModeBvh : (sc.n_objs <= kSmallObjs ? kModeLds : kModeTiled);
 }
@@ -645,7 +858,15 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
     const size_t lds = scene_lds_bytes(a.sc, mode);
     if (mode == kModeLds) launch_paths_mode<kModeLds>(a, grid, lds, st);
     else if (mode == kModeTiled) launch_paths_mode<kModeTiled>(a, grid, lds, st);
-    else launch_paths_mode<kModeBvh>(a, grid, lds, st);
+    else {
+        const bool mis = a.integrator == 0;
+        const bool ovf = a.src_mode != 0u;
+        const dim3 g(grid), b(kBlock);
+        if (mis && !ovf) hipLaunchKernelGGL((k_paths_bvh<true, false>), g, b, lds, st, a);
+        else if (mis) hipLaunchKernelGGL((k_paths_bvh<true, true>), g, b, lds, st, a);
+        else if (!ovf) hipLaunchKernelGGL((k_paths_bvh<false, false>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((k_paths_bvh<false, true>), g, b, lds, st, a);
+    }
 }
 }  // namespace ptk
 namespace PTK_IMPL {
@@ -703,16 +924,46 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float
             d = normalize(mk(rays6[6 * (size_t)i + 3], rays6[6 * (size_t)i + 4], rays6[6 * (size_t)i + 5]));
         }
         int id; float t;
-        if (MODE == kModeBvh) bvh_scan<false>(sc, active, o, d, t_min, t_max, id, t);
-        else scan_closest<MODE>(sc, o, d, t_min, t_max, id, t);
+        scan_closest<MODE>(sc, o, d, t_min, t_max, id, t);
         if (active) { out_id[i] = id; out_t[i] = id >= 0 ? t : 0.0f; }
+    }
+}
+// the same through the BVH: every wave packs a contiguous slice of the rays into segment form and runs
+// traverse_segment (the routine of k_paths_bvh) over it
+__global__ void __launch_bounds__(kBlock) k_debug_hit_bvh(SceneView scv, const float* __restrict__ rays6, uint32_t n,
+                                                          float t_min, float t_max, float4* p0, float4* p1, float4* res,
+                                                          int32_t* out_id, float* out_t) {
+    extern __shared__ float4 lds[];
+    const SceneRef sc = stage_scene<kModeBvh>(scv, lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (kBlock / 64);
+    const uint32_t slice = (n + nw - 1u) / nw;
+    const uint32_t base = wave * slice;
+    if (base >= n) return;
+    const uint32_t cnt = n - base < slice ? n - base : slice;
+    for (uint32_t k = lane; k < cnt; k += 64u) {
+        const size_t i = base + k;
+        const f3 o = mk(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]);
+        const f3 d = normalize(mk(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5]));
+        p0[i] = make_float4(o.x, o.y, o.z, d.x);
+        p1[i] = make_float4(d.y, d.z, t_max, 0.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    traverse_segment<true, false>(sc, p0 + base, p1 + base, res + base, cnt, t_min, kRefillBelow, kLeafBatch);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (uint32_t k = lane; k < cnt; k += 64u) {
+        const float4 r = res[base + k];
+        const int id = __float_as_int(r.x);
+        out_id[base + k] = id;
+        out_t[base + k] = id >= 0 ? r.y : 0.0f;
     }
 }
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
 void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min,
-                                 float t_max, int32_t* out_id, float* out_t, hipStream_t st) {
+                                 float t_max, float4* scratch, int32_t* out_id, float* out_t, hipStream_t st) {
     const int mode = scene_mode(sc, accel);
     const size_t lds = scene_lds_bytes(sc, mode);
     uint32_t grid = (n + kBlock - 1) / kBlock;
@@ -722,8 +973,9 @@ void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, uint32_t accel, const floa
         hipLaunchKernelGGL(k_debug_hit<kModeLds>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
     else if (mode == kModeTiled)
         hipLaunchKernelGGL(k_debug_hit<kModeTiled>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
-    else
-        hipLaunchKernelGGL(k_debug_hit<kModeBvh>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
+    else   // scratch: 3 planes of n float4 (two ray planes + result)
+        hipLaunchKernelGGL(k_debug_hit_bvh, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, scratch,
+                           scratch + n, scratch + 2 * (size_t)n, out_id, out_t);
 }
 
 }  // namespace ptk

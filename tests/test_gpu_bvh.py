@@ -158,3 +158,13 @@ def test_bvh_render_with_hand_off_and_bands(pt, gpu_ctx):
         prm = pt.default_params(spp=40, accel=accel, band_rows=32, band_index=1, band_count=2)
         films.append(gpu_ctx.render(cam, prm)[0].cpu().numpy())
     assert np.array_equal(films[0], films[1], equal_nan=True)
+
+
+def test_bvh_refuses_non_finite_objects(pt, gpu_ctx):
+    """accel = 1 with a NaN object: a status code, not a different picture (see tests/test_bvh_host.py)."""
+    specs = [(0, [0.0, 0.0, -2.0, 0.5], 1, [3.0, 3.0, 3.0]), (0, [float("nan"), 0.0, -2.0, 0.3], 0, [0.5, 0.5, 0.5])]
+    gpu_ctx.upload(pt.make_objects(specs))
+    cam = pt.camera_new(width=8, height=8)
+    gpu_ctx.render(cam, pt.default_params(spp=1, accel=0))
+    with pytest.raises(RuntimeError, match="NaN/inf"):
+        gpu_ctx.render(cam, pt.default_params(spp=1, accel=1))

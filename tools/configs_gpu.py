@@ -24,3 +24,8 @@ if "c4s" in which: run("C4 (4 spp probe)", pt.builtin_scene(4, 10000), 1024, 102
 if "c4" in which: run("C4", pt.builtin_scene(4, 10000), 1024, 1024, 256, reps=1)
 if "c5" in which: run("C5 on one GPU", pt.builtin_scene(2), 3840, 2160, 64, reps=1)
 if "c4m" in which: run("C4 (64 spp)", pt.builtin_scene(4, 10000), 1024, 1024, 64, reps=1)
+if "c4b" in which: run("C4 BVH (64 spp)", pt.builtin_scene(4, 10000), 1024, 1024, 64, reps=2, accel=1)
+if "c4bf" in which: run("C4 BVH", pt.builtin_scene(4, 10000), 1024, 1024, 256, reps=2, accel=1)
+if "c1b" in which: run("C1 BVH", pt.builtin_scene(1), 1024, 1024, 64, accel=1)
+if "c2b" in which: run("C2 BVH", pt.builtin_scene(2), 1024, 1024, 64, accel=1)
+if "c6b" in which: run("100k spheres BVH", pt.builtin_scene(4, 100000), 1024, 1024, 64, accel=1)
