@@ -162,6 +162,7 @@ int ensure_bvh(PtContext* c) {
     if (c->view.n_objs >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "accel: %u objects exceed the 2^28 leaf slots", c->view.n_objs);
     ptbvh::Built b = ptbvh::build(c->h_shape.data(), c->h_shape_tag.data(), c->view.n_objs);
     static_assert(ptbvh::kStackDepth == ptk::kBvhStack, "traversal stack depth");
+    static_assert(ptbvh::kMaxLeaf == ptk::kBvhMaxLeaf, "leaf size the traversal unrolls for");
     if (b.non_finite) return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate; the linear scan's answer for them "
                                   "depends on the scan order, use accel = 0", b.non_finite);
     if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);

@@ -607,7 +607,9 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
     uint32_t next = 0;                         // wave-uniform: first slot not handed out yet
     bool has = false;                          // this lane is tracing a ray
     uint32_t slot = 0, node = 0xFFFFFFFFu, sp = 1;
-    f3 o = parked_origin(), d = parked_dir(), inv = mk(0.f, 0.f, 0.f), op = o, om = o;
+    // slab planes as one FMA each: t = plane * inv + b with bp = -(o + pad) * inv for the lower plane of a box and
+    // bm = -(o - pad) * inv for the upper one (the rounding of b moves a plane by <= ulp(|o|), far inside pad)
+    f3 o = parked_origin(), d = parked_dir(), inv = mk(0.f, 0.f, 0.f), bp = inv, bm = inv;
     float a = 1.0f, inv_a = 1.0f, closest = 0.0f;
     int id = -1;
     for (;;) {
@@ -629,8 +631,9 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                     const bool regular = o1 + __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) + a + inv_a < kInf;
                     if (regular) {
                         const float pad = kBvhPad * (o1 + sc.bvh.scene_abs);
-                        op = mk(o.x + pad, o.y + pad, o.z + pad); om = mk(o.x - pad, o.y - pad, o.z - pad);
-                        inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                        inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // +-inf for a zero component
+                        bp = mk(-(o.x + pad) * inv.x, -(o.y + pad) * inv.y, -(o.z + pad) * inv.z);
+                        bm = mk(-(o.x - pad) * inv.x, -(o.y - pad) * inv.y, -(o.z - pad) * inv.z);
                         stk[0] = 0xFFFFFFFFu;
                         sp = 1;
                         node = sc.bvh.root;
@@ -653,16 +656,17 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
             if (has && (int)node >= 0) {                 // internal node: test both child boxes
                 const float4* nd = sc.bvh.nodes + 4u * node;
                 const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                float ax0 = (n0.x - op.x) * inv.x, ax1 = (n0.w - om.x) * inv.x;
-                float ay0 = (n0.y - op.y) * inv.y, ay1 = (n1.x - om.y) * inv.y;
-                float az0 = (n0.z - op.z) * inv.z, az1 = (n1.y - om.z) * inv.z;
+                // min/max drop the NaNs of inf - inf (a zero direction component): that axis then does not constrain
+                float ax0 = __builtin_fmaf(n0.x, inv.x, bp.x), ax1 = __builtin_fmaf(n0.w, inv.x, bm.x);
+                float ay0 = __builtin_fmaf(n0.y, inv.y, bp.y), ay1 = __builtin_fmaf(n1.x, inv.y, bm.y);
+                float az0 = __builtin_fmaf(n0.z, inv.z, bp.z), az1 = __builtin_fmaf(n1.y, inv.z, bm.z);
                 const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
                                                   __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
                 const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
                                                   __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
-                ax0 = (n1.z - op.x) * inv.x; ax1 = (n2.y - om.x) * inv.x;
-                ay0 = (n1.w - op.y) * inv.y; ay1 = (n2.z - om.y) * inv.y;
-                az0 = (n2.x - op.z) * inv.z; az1 = (n2.w - om.z) * inv.z;
+                ax0 = __builtin_fmaf(n1.z, inv.x, bp.x); ax1 = __builtin_fmaf(n2.y, inv.x, bm.x);
+                ay0 = __builtin_fmaf(n1.w, inv.y, bp.y); ay1 = __builtin_fmaf(n2.z, inv.y, bm.y);
+                az0 = __builtin_fmaf(n2.x, inv.z, bp.z); az1 = __builtin_fmaf(n2.w, inv.z, bm.z);
                 const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
                                                   __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
                 const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
@@ -686,16 +690,26 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
             if (leafs != 0ull && ((uint32_t)__popcll(leafs) >= leaf_batch || __ballot(has && (int)node >= 0) == 0ull)) {
                 if (at_leaf) {
                     const uint32_t first = node & 0x0FFFFFFFu, cnt = ((node >> 28) & 7u) + 1u;
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        const uint32_t w = sc.bvh.ids[first + i];
-                        const float4* rec = sc.bvh.rec + 3u * (first + i);
-                        const float4 r0 = rec[0];
-                        if ((int)w >= 0) {
-                            sphere_test<true>(r0, o, d, a, inv_a, t_min, closest, id, (int)w);
-                        } else {
-                            const float4 r1 = rec[1], r2 = rec[2];
-                            triangle_test<true>(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), o, d, t_min,
-                                                closest, id, (int)(w & 0x7FFFFFFFu));
+                    // all (<= 4) records requested before the first test: one memory latency per leaf
+                    uint32_t w[kBvhMaxLeaf];
+                    float4 r0[kBvhMaxLeaf];
+#pragma unroll
+                    for (uint32_t i = 0; i < kBvhMaxLeaf; ++i) {
+                        const uint32_t k = first + (i < cnt ? i : 0u);
+                        w[i] = sc.bvh.ids[k];
+                        r0[i] = sc.bvh.rec[3u * k];
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < kBvhMaxLeaf; ++i) {
+                        if (i < cnt) {
+                            if ((int)w[i] >= 0) {
+                                sphere_test<true>(r0[i], o, d, a, inv_a, t_min, closest, id, (int)w[i]);
+                            } else {
+                                const float4* rec = sc.bvh.rec + 3u * (first + i);
+                                const float4 r1 = rec[1], r2 = rec[2];
+                                triangle_test<true>(mk(r0[i].x, r0[i].y, r0[i].z), mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), o, d,
+                                                    t_min, closest, id, (int)(w[i] & 0x7FFFFFFFu));
+                            }
                         }
                     }
                     if (ANY && id >= 0) {

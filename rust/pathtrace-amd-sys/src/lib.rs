@@ -1,0 +1,110 @@
+//! Raw declarations of `include/pathtrace_amd.h` (ABI version 1).  Field order, types and names follow the
+//! header exactly; `tests/test_rust_binding.py` checks that.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const PT_ABI_VERSION: u32 = 1;
+
+pub const PT_OK: c_int = 0;
+pub const PT_ERR_INVALID_ARG: c_int = 1;
+pub const PT_ERR_NO_DEVICE: c_int = 2;
+pub const PT_ERR_HIP: c_int = 3;
+pub const PT_ERR_OOM: c_int = 4;
+pub const PT_ERR_UNSUPPORTED: c_int = 5;
+
+pub const PT_SHAPE_SPHERE: u32 = 0;
+pub const PT_SHAPE_TRIANGLE: u32 = 1;
+pub const PT_MAT_LAMBERT: u32 = 0;
+pub const PT_MAT_EMISSIVE: u32 = 1;
+pub const PT_MAT_MIRROR: u32 = 2;
+pub const PT_MAT_OREN_NAYAR: u32 = 3;
+pub const PT_INTEGRATOR_MIS: u32 = 0;
+pub const PT_INTEGRATOR_BRDF_ONLY: u32 = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtCamera {
+    pub origin: [f64; 3],
+    pub lower_left: [f64; 3],
+    pub horizontal: [f64; 3],
+    pub vertical: [f64; 3],
+    pub width: u32,
+    pub height: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct PtObject {
+    pub shape_tag: u32,
+    pub mat_tag: u32,
+    pub shape: [f64; 9],
+    pub mat: [f64; 6],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct PtRenderParams {
+    pub spp: u32,
+    pub spp_offset: u32,
+    pub min_depth: u32,
+    pub max_depth: u32,
+    pub integrator: u32,
+    pub t_min: f64,
+    pub band_rows: u32,
+    pub band_index: u32,
+    pub band_count: u32,
+    pub max_paths_in_flight: u64,
+    pub profile: u32,
+    pub workgroups: u32,
+    pub exact_math: u32,
+    pub accel: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtStats {
+    pub samples: u64,
+    pub vertices: u64,
+    pub shadow_rays: u64,
+    pub bounce_launches: u32,
+    pub batches: u32,
+    pub max_depth_reached: u32,
+    pub reserved: u32,
+    pub bounce_kernel_ms: f64,
+    pub total_ms: f64,
+    pub primary_vertices: u64,
+    pub primary_kernel_ms: f64,
+    pub primary_launches: u32,
+    pub reserved2: u32,
+}
+
+#[repr(C)]
+pub struct PtContext {
+    _private: [u8; 0],
+}
+
+pub type PtProgressFn = Option<
+    unsafe extern "C" fn(user: *mut c_void, spp_done: u32, spp_total: u32, rgba8: *const u8, linear_rgb: *const f32) -> c_int,
+>;
+
+extern "C" {
+    pub fn pt_camera_new(origin: *const f64, width: u32, height: u32, screen_distance: f64, fov_degrees: f64, out: *mut PtCamera) -> c_int;
+    pub fn pt_camera_look_at(origin: *const f64, target: *const f64, up: *const f64, width: u32, height: u32, fov_degrees: f64, out: *mut PtCamera) -> c_int;
+    pub fn pt_default_params(out: *mut PtRenderParams);
+    pub fn pt_tile_rows(height: u32, band_rows: u32, band_index: u32, band_count: u32) -> u32;
+    pub fn pt_builtin_scene(id: u32, arg: u32, objs: *mut PtObject, cap: u32, n: *mut u32) -> c_int;
+    pub fn pt_context_create(device: c_int, out: *mut *mut PtContext) -> c_int;
+    pub fn pt_context_destroy(ctx: *mut PtContext) -> c_int;
+    pub fn pt_context_set_stream(ctx: *mut PtContext, hip_stream: *mut c_void) -> c_int;
+    pub fn pt_scene_upload(ctx: *mut PtContext, objs: *const PtObject, n_objs: u32) -> c_int;
+    pub fn pt_render_device(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
+    pub fn pt_sync(ctx: *mut PtContext) -> c_int;
+    pub fn pt_get_stats(ctx: *mut PtContext, out: *mut PtStats) -> c_int;
+    pub fn pt_render_host(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_render_progressive(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, spp_step: u32, f: PtProgressFn, user: *mut c_void, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_render(cam: *const PtCamera, objs: *const PtObject, n_objs: u32, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_debug_hit_scene(ctx: *mut PtContext, rays: *const f64, n: u32, t_min: f64, t_max: f64, exact_math: u32, accel: u32, out_id: *mut i32, out_t: *mut f32) -> c_int;
+    pub fn pt_debug_bvh_check(objs: *const PtObject, n_objs: u32, depth: *mut u32, n_nodes: *mut u32, n_leaf_slots: *mut u32) -> c_int;
+    pub fn pt_last_error() -> *const c_char;
+    pub fn pt_abi_version() -> u32;
+}

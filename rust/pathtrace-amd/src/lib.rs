@@ -1,0 +1,125 @@
+//! Safe surface over `pathtrace-amd-sys`.  What the reference's render thread (`src/main.rs:42-60`) needs:
+//! describe the `World` once, render, get the two film buffers back (`World.data`, `World.luminance_data`,
+//! `src/world.rs:55-57`).  All `unsafe` of the integration is in this file.
+use pathtrace_amd_sys as sys;
+use std::ffi::CStr;
+
+pub use sys::{PtCamera as Camera, PtObject as Object, PtRenderParams as RenderParams, PtStats as Stats};
+
+#[derive(Debug)]
+pub struct Error {
+    pub code: i32,
+    pub message: String,
+}
+impl std::fmt::Display for Error {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "pathtrace_amd error {}: {}", self.code, self.message)
+    }
+}
+impl std::error::Error for Error {}
+
+fn check(code: i32) -> Result<(), Error> {
+    if code == sys::PT_OK {
+        return Ok(());
+    }
+    // pt_last_error() is thread-local and valid until the next failing call on this thread
+    let message = unsafe { CStr::from_ptr(sys::pt_last_error()) }.to_string_lossy().into_owned();
+    Err(Error { code, message })
+}
+
+/// `Object::new(Box<dyn Shape>, Box<dyn Material>)` flattened (`src/objects/object.rs:17-24`).
+pub fn sphere(center: [f64; 3], radius: f64, mat_tag: u32, mat: [f64; 6]) -> Object {
+    Object { shape_tag: sys::PT_SHAPE_SPHERE, mat_tag, shape: [center[0], center[1], center[2], radius, 0., 0., 0., 0., 0.], mat }
+}
+pub fn triangle(v0: [f64; 3], v1: [f64; 3], v2: [f64; 3], mat_tag: u32, mat: [f64; 6]) -> Object {
+    Object { shape_tag: sys::PT_SHAPE_TRIANGLE, mat_tag, shape: [v0[0], v0[1], v0[2], v1[0], v1[1], v1[2], v2[0], v2[1], v2[2]], mat }
+}
+
+/// Reference constants (`world.rs:18`, `rendering.rs:6-7`): spp 3000, depth 4..50, MIS, t_min 1e-3.
+pub fn default_params() -> RenderParams {
+    let mut p = std::mem::MaybeUninit::<RenderParams>::zeroed();
+    unsafe {
+        sys::pt_default_params(p.as_mut_ptr());
+        p.assume_init()
+    }
+}
+
+/// `Camera::new` (`src/camera.rs:50-82`).
+pub fn camera_new(origin: [f64; 3], width: u32, height: u32, screen_distance: f64, fov_degrees: f64) -> Result<Camera, Error> {
+    let mut cam = Camera::default();
+    check(unsafe { sys::pt_camera_new(origin.as_ptr(), width, height, screen_distance, fov_degrees, &mut cam) })?;
+    Ok(cam)
+}
+
+/// The two buffers `World::render_pixel` fills (`world.rs:318-332`), for one tile.
+pub struct Film {
+    pub width: u32,
+    pub rows: u32,
+    /// mean linear radiance, RGB f32, row-major (= `luminance_data`)
+    pub linear_rgb: Vec<f32>,
+    /// sqrt-gamma, truncated RGBA8 (= `World.data`, what `draw()` blits)
+    pub rgba8: Vec<u8>,
+}
+
+/// One GPU context with one uploaded scene.  Not `Sync`: use from one thread at a time (the reference's
+/// render thread); create one per GPU for multi-GPU band rendering.
+pub struct Renderer {
+    ctx: *mut sys::PtContext,
+}
+unsafe impl Send for Renderer {}
+
+impl Renderer {
+    pub fn new(device: i32) -> Result<Self, Error> {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { sys::pt_context_create(device, &mut ctx) })?;
+        Ok(Renderer { ctx })
+    }
+    /// Copies the scene (the reference's `World` is immutable while rendering, `world.rs:293`).
+    pub fn upload(&mut self, objects: &[Object]) -> Result<(), Error> {
+        check(unsafe { sys::pt_scene_upload(self.ctx, objects.as_ptr(), objects.len() as u32) })
+    }
+    /// Everything `main.rs:43-60` does for the tile selected by `params.band_*`; blocking.
+    pub fn render(&mut self, cam: &Camera, params: &RenderParams) -> Result<Film, Error> {
+        let band_count = params.band_count.max(1);
+        let rows = unsafe { sys::pt_tile_rows(cam.height, params.band_rows, params.band_index, band_count) };
+        let n = rows as usize * cam.width as usize;
+        let mut film = Film { width: cam.width, rows, linear_rgb: vec![0f32; n * 3], rgba8: vec![0u8; n * 4] };
+        check(unsafe { sys::pt_render_host(self.ctx, cam, params, film.linear_rgb.as_mut_ptr(), film.rgba8.as_mut_ptr()) })?;
+        Ok(film)
+    }
+    /// Progressive preview (`main.rs:79-90`): `on_frame(spp_done, spp_total, rgba8)` after every `spp_step`
+    /// samples; return `true` to stop.  The final film equals `render()`'s.
+    pub fn render_progressive<F: FnMut(u32, u32, &[u8]) -> bool>(
+        &mut self, cam: &Camera, params: &RenderParams, spp_step: u32, mut on_frame: F,
+    ) -> Result<Film, Error> {
+        struct Ctx<'a> {
+            f: &'a mut dyn FnMut(u32, u32, &[u8]) -> bool,
+            len: usize,
+        }
+        unsafe extern "C" fn tramp(user: *mut std::os::raw::c_void, done: u32, total: u32, rgba8: *const u8, _lin: *const f32) -> i32 {
+            let c = &mut *(user as *mut Ctx);
+            let px = std::slice::from_raw_parts(rgba8, c.len);
+            (c.f)(done, total, px) as i32
+        }
+        let band_count = params.band_count.max(1);
+        let rows = unsafe { sys::pt_tile_rows(cam.height, params.band_rows, params.band_index, band_count) };
+        let n = rows as usize * cam.width as usize;
+        let mut film = Film { width: cam.width, rows, linear_rgb: vec![0f32; n * 3], rgba8: vec![0u8; n * 4] };
+        let mut c = Ctx { f: &mut on_frame, len: n * 4 };
+        check(unsafe {
+            sys::pt_render_progressive(self.ctx, cam, params, spp_step, Some(tramp), &mut c as *mut Ctx as *mut _, film.linear_rgb.as_mut_ptr(), film.rgba8.as_mut_ptr())
+        })?;
+        Ok(film)
+    }
+    pub fn stats(&mut self) -> Result<Stats, Error> {
+        let mut s = Stats::default();
+        check(unsafe { sys::pt_get_stats(self.ctx, &mut s) })?;
+        Ok(s)
+    }
+}
+
+impl Drop for Renderer {
+    fn drop(&mut self) {
+        unsafe { sys::pt_context_destroy(self.ctx) };
+    }
+}

@@ -1,0 +1,69 @@
+"""The Rust -sys crate (rust/pathtrace-amd-sys) is source only here -- no cargo/rustc in the image.
+What can be checked without a compiler is that it declares exactly the header's ABI: every function with the
+same argument count, every struct with the same fields in the same order and the same scalar types."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "pathtrace_amd.h")).read()
+RUST = open(os.path.join(ROOT, "rust", "pathtrace-amd-sys", "src", "lib.rs")).read()
+
+C2RUST = {"double": "f64", "float": "f32", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "uint8_t": "u8", "int": "c_int"}
+
+
+def _strip_comments(src):
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def _c_functions():
+    out = {}
+    for m in re.finditer(r"^(?:const\s+)?[a-z_0-9A-Z]+\*?\s+\**(pt_[a-z_]+)\(([^;]*?)\);", _strip_comments(HEADER), flags=re.M | re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def _rust_functions():
+    out = {}
+    for m in re.finditer(r"pub fn (pt_[a-z_]+)\((.*?)\)\s*(?:->[^;]+)?;", RUST, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_every_header_function_is_declared_with_the_same_arity():
+    c, r = _c_functions(), _rust_functions()
+    assert len(c) >= 19 and "pt_render_device" in c and "pt_debug_bvh_check" in c
+    assert c == r
+
+
+def _c_struct(name):
+    body = re.search(r"typedef struct \{([^}]*)\} %s;" % name, _strip_comments(HEADER)).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(\w+)\s+(.*)", decl)
+        for var in m.group(2).split(","):
+            var = var.strip()
+            am = re.match(r"(\w+)\[(\d+)\]", var)
+            fields.append((am.group(1), "[%s; %s]" % (C2RUST[m.group(1)], am.group(2))) if am else (var, C2RUST[m.group(1)]))
+    return fields
+
+
+def _rust_struct(name):
+    body = re.search(r"pub struct %s \{(.*?)\}" % name, RUST, flags=re.S).group(1)
+    return [(m.group(1), m.group(2).strip()) for m in re.finditer(r"pub (\w+): ([^,]+),", body)]
+
+
+def test_struct_fields_match_the_header():
+    for name in ("PtCamera", "PtObject", "PtRenderParams", "PtStats"):
+        assert _c_struct(name) == _rust_struct(name), name
+
+
+def test_constants_match_the_header():
+    hdr = _strip_comments(HEADER)
+    for m in re.finditer(r"(PT_(?:OK|ERR|SHAPE|MAT|INTEGRATOR)_?\w*)\s*=\s*(\d+)", hdr):
+        assert re.search(r"pub const %s: \w+ = %s;" % (m.group(1), m.group(2)), RUST), m.group(1)
+    assert re.search(r"#define PT_ABI_VERSION (\d+)", HEADER).group(1) == re.search(r"PT_ABI_VERSION: u32 = (\d+);", RUST).group(1)
