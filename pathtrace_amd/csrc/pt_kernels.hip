@@ -631,7 +631,11 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                     const bool regular = o1 + __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) + a + inv_a < kInf;
                     if (regular) {
                         const float pad = kBvhPad * (o1 + sc.bvh.scene_abs);
-                        inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // +-inf for a zero component
+                        // 1/d clamped to +-1e25: a zero (or denormal) component then acts like +-infinity without the
+                        // inf - inf = NaN an FMA would make of it (one NaN plane and min/max collapse the slab interval)
+                        inv = mk(__builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(d.x), -1e25f), 1e25f),
+                                 __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(d.y), -1e25f), 1e25f),
+                                 __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(d.z), -1e25f), 1e25f));
                         bp = mk(-(o.x + pad) * inv.x, -(o.y + pad) * inv.y, -(o.z + pad) * inv.z);
                         bm = mk(-(o.x - pad) * inv.x, -(o.y - pad) * inv.y, -(o.z - pad) * inv.z);
                         stk[0] = 0xFFFFFFFFu;
@@ -656,7 +660,6 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
             if (has && (int)node >= 0) {                 // internal node: test both child boxes
                 const float4* nd = sc.bvh.nodes + 4u * node;
                 const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                // min/max drop the NaNs of inf - inf (a zero direction component): that axis then does not constrain
                 float ax0 = __builtin_fmaf(n0.x, inv.x, bp.x), ax1 = __builtin_fmaf(n0.w, inv.x, bm.x);
                 float ay0 = __builtin_fmaf(n0.y, inv.y, bp.y), ay1 = __builtin_fmaf(n1.x, inv.y, bm.y);
                 float az0 = __builtin_fmaf(n0.z, inv.z, bp.z), az1 = __builtin_fmaf(n1.y, inv.z, bm.z);
