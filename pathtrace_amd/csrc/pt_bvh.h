@@ -17,7 +17,7 @@ namespace ptbvh {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kDone = 0xFFFFFFFFu;      // stack sentinel / root of an empty scene (no leaf code: a leaf holds <= 4 primitives)
 constexpr uint32_t kMaxLeaf = 4;             // primitives per leaf
-constexpr uint32_t kStackDepth = 32;         // traversal stack entries per lane (LDS); the builder keeps the tree this shallow
+constexpr uint32_t kStackDepth = 24;         // traversal stack entries per lane (LDS); the builder keeps the tree this shallow (<= 16 M objects)
 constexpr uint32_t kTriangleBit = 0x80000000u;   // in leaf_ids: the primitive is a triangle
 
 struct Built {

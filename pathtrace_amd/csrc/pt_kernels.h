@@ -99,7 +99,7 @@ constexpr uint32_t kTileF4 = 2550;         // 39.8 KiB LDS tile (divisible by 3:
 constexpr uint32_t kRefillBelow = 36;      // BVH traversal: hand out new rays when fewer lanes than this are tracing
 constexpr uint32_t kLeafBatch = 24;        // BVH traversal: test leaf primitives when at least this many lanes wait at a leaf
 constexpr uint32_t kBvhMaxLeaf = 4;        // primitives per BVH leaf the traversal unrolls for (= ptbvh::kMaxLeaf)
-constexpr uint32_t kBvhStack = 32;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 32 KiB per workgroup
+constexpr uint32_t kBvhStack = 24;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 24 KiB per workgroup, 5 workgroups per CU
 
 // One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
 // (4 queue segments each).  _exact / _fast: the two arithmetic modes of pt_device.h

@@ -733,7 +733,7 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
 }
 
 #ifndef PT_BVH_WAVES
-#define PT_BVH_WAVES 4
+#define PT_BVH_WAVES 5      // measured on C4: 4 -> 74.0 ms, 5 -> 70.2 ms, 6 (spills) -> 72.8 ms
 #endif
 template <bool MIS, bool OVF>
 __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a) {

@@ -13,7 +13,7 @@ def test_builtin_scenes(pt, scene, arg):
     objs = pt.builtin_scene(scene, arg)
     depth, nodes, slots = pt.bvh_check(objs)
     assert slots == len(objs)
-    assert depth <= 30
+    assert depth <= 22
     if len(objs) > 4:
         assert nodes >= (len(objs) + 3) // 4 - 1 and nodes < len(objs)
         assert depth <= 3 * int(np.ceil(np.log2(len(objs))))        # SAH on these scenes stays near balanced
@@ -43,7 +43,7 @@ def test_coincident_centroids_fall_back_to_median_splits(pt):
     n = 5000
     objs = pt.make_objects([(0, [0.25, -0.5, -2.0, 0.1 + 1e-4 * (i % 7)], 0, [0.5, 0.5, 0.5]) for i in range(n)])
     depth, nodes, slots = pt.bvh_check(objs)
-    assert slots == n and depth <= 30
+    assert slots == n and depth <= 22
     assert depth == int(np.ceil(np.log2(n / 4)))           # pure object-median tree
 
 
@@ -59,7 +59,7 @@ def test_clustered_scene_depth_is_bounded(pt):
             specs.append((0, list(c) + [0.01 * scale], 0, [0.5, 0.5, 0.5]))
         scale *= 0.5
     depth, nodes, slots = pt.bvh_check(pt.make_objects(specs))
-    assert slots == len(specs) and depth <= 30
+    assert slots == len(specs) and depth <= 22
 
 
 def test_non_finite_objects_are_refused(pt):
