@@ -41,7 +41,7 @@ WORKLOADS = {
     "c1": (1, 0, 1024, 1024, 64, "C1: reference Cornell box + GGX glass sphere (World::new(), 13 objects)"),
     "c2": (2, 0, 1024, 1024, 64, "C2: 10-sphere diffuse Cornell scene"),
     "c3": (2, 0, 1024, 1024, 4096, "C3: 10-sphere diffuse Cornell scene, steady state"),
-    "c4": (4, 10000, 1024, 1024, 256, "C4: 10 000 random spheres (100 lights), brute-force LDS-tiled scan"),
+    "c4": (4, 10000, 1024, 1024, 256, "C4: 10 000 random spheres (100 lights)"),
     "c5": (2, 0, 3840, 2160, 1024, "C5: 10-sphere diffuse Cornell scene, 4K"),
 }
 BYTES_PER_VERTEX = 252      # extend 32 + shade 144 + shadow/accumulate 68 + compaction 8
@@ -238,8 +238,10 @@ def main():
                                                           f"ONE {args.backend} gather of the packed f32 + RGBA8 frame to rank 0 per step",
             },
             "roofline": {
-                "kernel": "k_paths<SMALL, MIS, OVF=false>: the level-0 launch of a sample batch (camera rays + every "
-                          "bounce until the waves hand over their sparse tails), rank 0",
+                "kernel": ("k_paths_bvh<MIS, OVF=false>" if args.accel else
+                           ("k_paths<kModeLds, MIS, OVF=false>" if len(objs) <= 128 else "k_paths<kModeTiled, MIS, OVF=false>")) +
+                          ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
+                          "over their sparse tails), rank 0",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

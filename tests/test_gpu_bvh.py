@@ -168,3 +168,17 @@ def test_bvh_refuses_non_finite_objects(pt, gpu_ctx):
     gpu_ctx.render(cam, pt.default_params(spp=1, accel=0))
     with pytest.raises(RuntimeError, match="NaN/inf"):
         gpu_ctx.render(cam, pt.default_params(spp=1, accel=1))
+
+
+def test_bvh_render_in_several_batches(pt, gpu_ctx):
+    """spp split into sample batches by max_paths_in_flight (f64 film sums across batches), BVH vs linear."""
+    objs = pt.builtin_scene(4, 400)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_new(width=64, height=64)
+    films = []
+    for accel, cap in ((0, 0), (1, 64 * 64 * 3), (1, 64 * 64 * 7)):
+        prm = pt.default_params(spp=16, accel=accel, max_paths_in_flight=cap)
+        films.append(gpu_ctx.render(cam, prm)[0].cpu().numpy())
+        if cap:
+            assert gpu_ctx.stats().batches == -(-16 // (cap // (64 * 64)))
+    assert np.array_equal(films[0], films[1], equal_nan=True) and np.array_equal(films[0], films[2], equal_nan=True)
