@@ -74,7 +74,7 @@ struct BounceArgs {
     // accel = 1 only (k_paths_bvh): per-slot scratch of the staged passes, same indexing as q
     float4* aux;              // (closest-hit id, t, occluded, -)
     float4* sray0;            // shadow ray (o, d.x)
-    float4* sray1;            // (d.y, d.z, t_max or -1 = none, -)
+    float4* sray1;            // (d.y, d.z, t_max, 1 = the slot has a shadow ray)
     float4* lsamp;            // per-path final radiance, index = s_local*np + tile_row*width + x
     unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)  [3] vertices of level-0 launches
     TileMap tile;

@@ -595,8 +595,9 @@ __global__ void __launch_bounds__(kBlock, PT_BOUNCE_WAVES) k_paths(BounceArgs a)
 //     stage 4  shade    vertex_begin again (cheaper than storing it) + vertex_end, in-place compaction
 // Pass 0 first writes the camera rays (or the overflow queue's paths) into the segment.
 
-// Rays of a segment: plane0[slot] = (o, d.x), plane1[slot] = (d.y, d.z, t_max if TMAX_IN_RAY, -); a negative
-// t_max marks a slot without a ray.  ANY: out[slot].z = 1 if anything is hit, else 0 (visibility).  Otherwise
+// Rays of a segment: plane0[slot] = (o, d.x), plane1[slot] = (d.y, d.z, t_max, has_ray) when TMAX_IN_RAY (a slot
+// with has_ray == 0 is skipped; t_max itself may be anything, also negative or NaN -- the scan's semantics
+// decide), else plane1[slot] = (d.y, d.z, -, -) and t_max = inf.  ANY: out[slot].z = 1 if anything is hit, else 0 (visibility).  Otherwise
 // out[slot].xy = (id, t) of the closest hit.  Semantics of one ray: bvh_scan.
 template <bool TMAX_IN_RAY, bool ANY>
 PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plane0, const float4* __restrict__ plane1,
@@ -620,7 +621,7 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
             if (!has && cand < n) {
                 const float4 r0 = plane0[cand], r1 = plane1[cand];
                 const float t_max = TMAX_IN_RAY ? r1.z : kInf;
-                if (!TMAX_IN_RAY || t_max >= 0.0f) {
+                if (!TMAX_IN_RAY || r1.w != 0.0f) {
                     slot = cand;
                     o = mk(r0.x, r0.y, r0.z); d = mk(r0.w, r1.x, r1.y);
                     a = dot(d, d);
@@ -791,7 +792,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 vertex_begin<true>(sc, p, active, __float_as_int(h.x), h.y, a.s_base + p.s_local, image_row(a.tile, p.yl), v);
                 if (active) {
                     sr0[s] = make_float4(v.hit.point.x, v.hit.point.y, v.hit.point.z, v.light_dir.x);
-                    sr1[s] = make_float4(v.light_dir.y, v.light_dir.z, v.need_shadow ? v.distance - a.t_min : -1.0f, 0.f);
+                    sr1[s] = make_float4(v.light_dir.y, v.light_dir.z, v.distance - a.t_min, v.need_shadow ? 1.0f : 0.0f);
                 }
                 wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
@@ -964,7 +965,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit_bvh(SceneView scv, const f
         const f3 o = mk(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]);
         const f3 d = normalize(mk(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5]));
         p0[i] = make_float4(o.x, o.y, o.z, d.x);
-        p1[i] = make_float4(d.y, d.z, t_max, 0.f);
+        p1[i] = make_float4(d.y, d.z, t_max, 1.0f);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     traverse_segment<true, false>(sc, p0 + base, p1 + base, res + base, cnt, t_min, kRefillBelow, kLeafBatch);

@@ -182,3 +182,55 @@ def test_bvh_render_in_several_batches(pt, gpu_ctx):
         if cap:
             assert gpu_ctx.stats().batches == -(-16 // (cap // (64 * 64)))
     assert np.array_equal(films[0], films[1], equal_nan=True) and np.array_equal(films[0], films[2], equal_nan=True)
+
+
+def test_full_size_c4_bvh_film_equals_linear_scan_film(pt, gpu_ctx):
+    """BASELINE config C4 at full size -- 10 000 spheres, 1024^2, 256 spp (2.7e8 samples, 4 sample batches), default
+    arithmetic: the BVH render and the brute-force render give the same film bit for bit and count the same
+    vertices and shadow rays."""
+    gpu_ctx.upload(pt.builtin_scene(4, 10000))
+    cam = pt.camera_new(width=1024, height=1024)
+    out = []
+    for accel in (1, 0):
+        lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=256, accel=accel))
+        st = gpu_ctx.stats()
+        out.append((lin.cpu().numpy(), rgba.cpu().numpy(), (st.samples, st.vertices, st.shadow_rays, st.max_depth_reached, st.batches)))
+    assert out[0][2][0] == 1024 * 1024 * 256 and out[0][2][4] == 4
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1])
+    assert np.isfinite(out[0][0]).all()
+
+
+def test_bvh_film_does_not_depend_on_traversal_scheduling(pt, gpu_ctx, monkeypatch):
+    """Which lane traces which ray (refill threshold, leaf batching, number of queue segments) must not matter."""
+    gpu_ctx.upload(pt.builtin_scene(4, 3000))
+    cam = pt.camera_new(width=256, height=128)
+    ref, ref8 = gpu_ctx.render(cam, pt.default_params(spp=8, accel=1))
+    ref, ref8 = ref.cpu().numpy(), ref8.cpu().numpy()
+    for refill, leaf, wg in [("1", "1", 0), ("64", "64", 0), ("20", "3", 0), ("36", "24", 7), ("50", "40", 999)]:
+        monkeypatch.setenv("PT_BVH_REFILL", refill)
+        monkeypatch.setenv("PT_BVH_LEAF", leaf)
+        lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=8, accel=1, workgroups=wg))
+        assert np.array_equal(lin.cpu().numpy(), ref) and np.array_equal(rgba.cpu().numpy(), ref8), (refill, leaf, wg)
+
+
+@pytest.mark.parametrize("t_min", [0.3, 0.05, 1e-6])
+def test_bvh_with_unusual_t_min(pt, gpu_ctx, t_min):
+    """A large t_min makes `distance - t_min` (the shadow ray's t_max, rendering.rs:64) negative or tiny for many
+    light samples: the scan then finds nothing (empty interval) and the light counts as visible.  The BVH path
+    must agree -- also in what it does with slots that have no shadow ray at all."""
+    rng = np.random.default_rng(3)
+    for objs in (pt.builtin_scene(4, 600), random_scene(pt, rng, 200), pt.builtin_scene(1)):
+        gpu_ctx.upload(objs)
+        cam = pt.camera_new(width=96, height=64)
+        out = []
+        for accel in (0, 1):
+            lin, _ = gpu_ctx.render(cam, pt.default_params(spp=8, accel=accel, t_min=t_min))
+            st = gpu_ctx.stats()
+            out.append((lin.cpu().numpy(), st.vertices, st.shadow_rays))
+        assert np.array_equal(out[0][0], out[1][0], equal_nan=True), t_min
+        assert out[0][1:] == out[1][1:]
+    rays = _rays(rng, 50_000)
+    gpu_ctx.upload(pt.builtin_scene(4, 600))
+    for t_max in (-0.5, 0.0, 0.5 * t_min, float("nan")):
+        _same_hits(gpu_ctx, rays, t_min, t_max)
