@@ -44,19 +44,59 @@ def gather_tiles(tile, height, band_rows, rank, world_size, group=None, dst=0):
     return frame
 
 
+class FilmGather:
+    """The per-frame exchange with everything that does not change from frame to frame done once: row
+    partition, padded send tile, receive buffer and the row permutation that puts the gathered band rows in
+    image order.  Per frame: two pack copies, ONE dist.gather, one index_select, two unpack copies -- no Python
+    loop over rows, no host-to-device copy.
+
+    Both film planes travel together: the f32 linear plane [rows, W, 3] and the RGBA8 plane [rows, W, 4] are
+    packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel)."""
+
+    def __init__(self, height, width, band_rows, rank, world_size, device, group=None, dst=0):
+        rows = [tile_row_indices(height, band_rows, g, world_size) for g in range(world_size)]
+        self.height, self.width, self.rank, self.world, self.group, self.dst = height, width, rank, world_size, group, dst
+        self.my_rows = len(rows[rank])
+        self.max_rows = max(len(r) for r in rows)
+        self.send = torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device)
+        self.recv = self.bufs = self.perm = None
+        if rank == dst:
+            self.recv = torch.empty((world_size, self.max_rows, width, 16), dtype=torch.uint8, device=device)
+            self.bufs = [self.recv[g] for g in range(world_size)]
+            perm = [0] * height
+            for g in range(world_size):
+                for k, y in enumerate(rows[g]):
+                    perm[y] = g * self.max_rows + k
+            self.perm = torch.tensor(perm, dtype=torch.int64).to(device)
+
+    def __call__(self, lin, rgba):
+        """(linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`, (None, None) elsewhere."""
+        n, w = self.my_rows, self.width
+        assert lin.shape[0] == n and rgba.shape[0] == n, (lin.shape, rgba.shape, n)
+        self.send[:n, :, :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(n, w, 12)
+        self.send[:n, :, 12:] = rgba
+        if self.world == 1:
+            frame = self.send.index_select(0, self.perm)
+        else:
+            dist.gather(self.send, gather_list=self.bufs, dst=self.dst, group=self.group)
+            if self.rank != self.dst:
+                return None, None
+            frame = self.recv.view(self.world * self.max_rows, w, 16).index_select(0, self.perm)
+        lin_full = frame[..., :12].contiguous().reshape(-1).view(torch.float32).reshape(self.height, w, 3)
+        return lin_full, frame[..., 12:].contiguous()
+
+
+_plans = {}
+
+
 def gather_film(lin, rgba, height, band_rows, rank, world_size, group=None, dst=0):
-    """ONE collective for both film planes: the f32 linear plane [rows, W, 3] and the RGBA8 plane
-    [rows, W, 4] are packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel), gathered once and
-    unpacked on `dst`.  Returns (linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`, (None, None) elsewhere."""
-    rows, width = lin.shape[0], lin.shape[1]
-    packed = torch.empty((rows, width, 16), dtype=torch.uint8, device=lin.device)
-    packed[..., :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(rows, width, 12)
-    packed[..., 12:] = rgba
-    frame = gather_tiles(packed, height, band_rows, rank, world_size, group, dst)
-    if frame is None:
-        return None, None
-    lin_full = frame[..., :12].contiguous().reshape(-1).view(torch.float32).reshape(height, width, 3)
-    return lin_full, frame[..., 12:].contiguous()
+    """ONE collective for both film planes (FilmGather; the plan is cached per geometry and device).
+    Returns (linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`, (None, None) elsewhere."""
+    key = (height, lin.shape[1], band_rows, rank, world_size, str(lin.device), id(group), dst)
+    plan = _plans.get(key)
+    if plan is None:
+        plan = _plans[key] = FilmGather(height, lin.shape[1], band_rows, rank, world_size, lin.device, group, dst)
+    return plan(lin, rgba)
 
 
 def render_distributed(ctx, cam, params, rank, world_size, band_rows=None, group=None, want_rgba=True):

@@ -10,6 +10,11 @@ for dtype, shape in ((torch.float32, (64, 1024, 3)), (torch.uint8, (64, 1024, 4)
     out = [torch.empty_like(t)]
     dist.gather(t, gather_list=out, dst=0)
     assert torch.equal(out[0], t), dtype
+# FilmGather's form: uint8 [rows, W, 16] tile gathered into views of one contiguous receive buffer
+send = (torch.rand((128, 1024, 16), device=dev) * 255).to(torch.uint8)
+recv = torch.empty((1, 128, 1024, 16), dtype=torch.uint8, device=dev)
+dist.gather(send, gather_list=[recv[0]], dst=0)
+assert torch.equal(recv[0], send)
 x = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(x, op=dist.ReduceOp.MAX); assert x.item() == 1.5
 y = torch.tensor([3.0, 4.0], dtype=torch.float64, device=dev); dist.all_reduce(y, op=dist.ReduceOp.SUM); assert y.tolist() == [3.0, 4.0]
 dist.barrier()
