@@ -654,6 +654,14 @@ inline void mirror_sample(const Obj<R>& m, const Ray<R>& ray, const V3<R>& n, R 
 }
 
 // ---- OrenNayar eval, material.rs:221-265
+// f32 specification of cos(phi_i - phi_o): cosine of the angle between the tangent-plane projections (no
+// atan2 / cos, whose float results differ between libm and the device's libdevice); u = (1, 0) for a zero
+// projection, as atan2(0, 0) = 0.
+inline void unit_azimuth_f32(float x, float y, float& ux, float& uy) {
+    float l2 = std::fmaf(y, y, x * x);
+    if (l2 > 0.0f) { float inv = 1.0f / std::sqrt(l2); ux = x * inv; uy = y * inv; }
+    else { ux = 1.0f; uy = 0.0f; }
+}
 template <class R>
 inline void oren_nayar_eval(const Obj<R>& m, const Ray<R>& ray, const V3<R>& o, const V3<R>& n, V3<R>& f, R& pdf) {
     V3<R> i = -ray.direction;
@@ -662,9 +670,17 @@ inline void oren_nayar_eval(const Obj<R>& m, const Ray<R>& ray, const V3<R>& o, 
     R so = std::sqrt(std::fmax(R(1) - co * co, R(0)));
     V3<R> tangent, bitangent;
     frame_of(n, tangent, bitangent);     // compute_tangent :210-217, bitangent = n x t :203
-    R phi_i = std::atan2(i.dot(bitangent), i.dot(tangent));
-    R phi_o = std::atan2(o.dot(bitangent), o.dot(tangent));
-    R cos_phi = std::fmax(std::cos(phi_i - phi_o), R(0));
+    R cos_phi;
+    if (Ar<R>::kFloat) {
+        float uix, uiy, uox, uoy;
+        unit_azimuth_f32((float)i.dot(tangent), (float)i.dot(bitangent), uix, uiy);
+        unit_azimuth_f32((float)o.dot(tangent), (float)o.dot(bitangent), uox, uoy);
+        cos_phi = (R)std::fmax(std::fmaf(uiy, uoy, uix * uox), 0.0f);
+    } else {
+        R phi_i = std::atan2(i.dot(bitangent), i.dot(tangent));   // material.rs:246-247
+        R phi_o = std::atan2(o.dot(bitangent), o.dot(tangent));
+        cos_phi = std::fmax(std::cos(phi_i - phi_o), R(0));       // :249
+    }
     R sin_alpha, tan_beta;
     if (ci > co) { tan_beta = ci > R(1e-6) ? si / ci : R(0); sin_alpha = so; }
     else { tan_beta = co > R(1e-6) ? so / co : R(0); sin_alpha = si; }

@@ -404,8 +404,14 @@ PT_DEV void mirror_sample(const Mat& m, f3 dir_in, float eta, f3 n, float r1, fl
         wo = on; f = btdf; pdf = p; cos_out = o_n;
     }
 }
-// OrenNayar::bsdf_pdf, material.rs:221-265 (atan2f/cosf are libdevice: the one
-// material whose f32 result is not bit-reproducible on the host)
+// OrenNayar::bsdf_pdf, material.rs:221-265.  The reference takes cos(phi_i - phi_o) of two atan2 azimuths
+// (:246-249); the f32 specification uses the same number without trigonometry: the cosine of the angle between
+// the tangent-plane projections, cos dphi = u_i . u_o with u = p/|p| (and u = (1, 0) for p = 0, as atan2(0, 0) = 0).
+PT_DEV void unit_azimuth(float x, float y, float& ux, float& uy) {
+    float l2 = __builtin_fmaf(y, y, x * x);
+    if (l2 > 0.0f) { float inv = pt_rcp(pt_sqrt(l2)); ux = x * inv; uy = y * inv; }
+    else { ux = 1.0f; uy = 0.0f; }
+}
 PT_DEV void oren_nayar_eval(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) {
     f3 i = -dir_in;
     float ci = __builtin_fmaxf(dot(i, n), 0.0f), co = __builtin_fmaxf(dot(o, n), 0.0f);
@@ -413,9 +419,10 @@ PT_DEV void oren_nayar_eval(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& p
     float so = pt_sqrt(__builtin_fmaxf(1.0f - co * co, 0.0f));
     f3 tangent, bitangent;
     frame_of(n, tangent, bitangent);
-    float phi_i = atan2f(dot(i, bitangent), dot(i, tangent));
-    float phi_o = atan2f(dot(o, bitangent), dot(o, tangent));
-    float cos_phi = __builtin_fmaxf(cosf(phi_i - phi_o), 0.0f);
+    float uix, uiy, uox, uoy;
+    unit_azimuth(dot(i, tangent), dot(i, bitangent), uix, uiy);
+    unit_azimuth(dot(o, tangent), dot(o, bitangent), uox, uoy);
+    float cos_phi = __builtin_fmaxf(__builtin_fmaf(uiy, uoy, uix * uox), 0.0f);
     float sin_alpha, tan_beta;
     if (ci > co) { tan_beta = ci > 1e-6f ? pt_div(si, ci) : 0.0f; sin_alpha = so; }
     else { tan_beta = co > 1e-6f ? pt_div(so, co) : 0.0f; sin_alpha = si; }

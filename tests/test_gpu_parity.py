@@ -108,7 +108,15 @@ def test_metal_and_oren_nayar_materials(pt, orc, gpu_ctx):
     on = pt.make_objects([(0, [0.4, -0.6, -2.0, 0.4], 3, [0.7, 0.7, 0.7, 0.5])])[0]
     objs[7] = on
     arr = (pt._lib.PtObject * len(objs))(*objs)
-    _check(pt, orc, gpu_ctx, arr, pt.camera_new(width=64, height=64), pt.default_params(spp=8), exact=False)
+    _check(pt, orc, gpu_ctx, arr, pt.camera_new(width=64, height=64), pt.default_params(spp=8))
+    # a scene of OrenNayar surfaces only (all walls and spheres), rough and smooth
+    on_objs = list(pt.builtin_scene(2))
+    for k, o in enumerate(on_objs):
+        if o.mat_tag == 0:
+            o.mat_tag = 3
+            o.mat[3] = [0.0, 0.3, 0.6, 1.0][k % 4]
+    arr = (pt._lib.PtObject * len(on_objs))(*on_objs)
+    _check(pt, orc, gpu_ctx, arr, pt.camera_new(width=64, height=64), pt.default_params(spp=8))
 
 
 def test_no_lights_and_empty_scene(pt, orc, gpu_ctx):
