@@ -186,6 +186,10 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
     int id = -1;
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         Run run = sc.runs[r];
+        // the run record is the same in every lane: keep it (and the loop counters and object indices derived
+        // from it) in scalar registers
+        run.tag = __builtin_amdgcn_readfirstlane(run.tag); run.first_obj = __builtin_amdgcn_readfirstlane(run.first_obj);
+        run.count = __builtin_amdgcn_readfirstlane(run.count); run.off4 = __builtin_amdgcn_readfirstlane(run.off4);
         const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
         if (SMALL) {
             scan_run<false>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
