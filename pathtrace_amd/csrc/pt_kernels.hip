@@ -1,8 +1,7 @@
 // pt_kernels.hip -- HIP kernels of the wavefront path tracer, gfx950 (wave64).
 //
-// One launch of k_bounce advances every queued path by ONE vertex of
-// MisStrategy::ray_color / BrdfOnlyStrategy::ray_color (src/rendering.rs:34-142,
-// 214-265) in the iterative order of SURVEY 3.5:
+// Every path vertex is one level of MisStrategy::ray_color / BrdfOnlyStrategy::ray_color
+// (src/rendering.rs:34-142, 214-265) in the iterative order of SURVEY 3.5:
 //     closest hit of the path ray            World::hit_scene      world.rs:270-290
 //     miss -> retire; emitter -> credit (MIS look-ahead weight), retire
 //     NEE: pick light, sample its surface    World::sample_light_point  world.rs:251-267
@@ -10,14 +9,21 @@
 //     BSDF sample, throughput, Russian roulette                    rendering.rs:83-102
 //     survivors are compacted in place into the wave's own queue segment (wave64 ballot
 //     + prefix popcount, no atomics); retired paths store their radiance to lsamp[pid].
-// Bounce 0 generates the camera ray itself (Camera::get_ray_with_offset,
-// camera.rs:139-147; jitter draws world.rs:299) instead of reading the queue.
+// (vertex_begin / vertex_end below; shared by both path kernels.)
 //
-// Data layout: path state = 4 float4 planes (SoA of float4 -> every lane moves
-// 16 B per instruction, 1 KiB per wave-instruction); scene primitives are staged
-// in LDS and read by all 64 lanes at the same address (broadcast, conflict-free).
-// The grid is persistent (one queue segment per wave, lengths kept in device memory),
-// so no host round-trip sits between bounces.
+// Kernels:
+//   k_paths<MODE, MIS, OVF>   one launch traces a whole sample batch, every bounce; hit_scene is the reference's
+//                             linear scan, out of LDS (MODE = kModeLds, scenes <= 128 objects) or streamed through
+//                             an LDS tile (kModeTiled).  Pass 0 generates the camera rays (camera.rs:139-147,
+//                             world.rs:299) or, in a continuation launch (OVF), takes over the overflow queue.
+//   k_paths_bvh<MIS, OVF>     the same for PtRenderParams.accel = 1: hit_scene by BVH traversal, each pass cut into
+//                             extend / connect / occlude / shade stages with per-lane ray refill.
+//   k_resolve                 film: per-pixel f64 sum in sample order, mean, gamma, RGBA8 (world.rs:311-332).
+//   k_debug_hit[_bvh]         hit_scene on arbitrary rays (parity tests).
+//
+// Data layout: path state = 4 float4 planes (SoA of float4 -> every lane moves 16 B per instruction, 1 KiB per
+// wave-instruction); small scenes live in LDS and are read by all 64 lanes at the same address (broadcast,
+// conflict-free).  Grids are persistent (one queue segment per wave), so no host round trip sits between bounces.
 #include "pt_device.h"
 #include "pt_kernels.h"
 
