@@ -77,6 +77,12 @@ def cpu_baseline(pt, objs):
     spp = SPP if (HEIGHT // band_count) * WIDTH * SPP / rate <= 30.0 else int(max(1, 30.0 * rate / (64 * WIDTH)))
     rows, dt = run(spp, band_count)
     samples = rows * WIDTH * spp
+    # BASELINE.json configs[0]: the reference's own scene, 256 x 256, 4 spp, ONE thread (the scalar port)
+    c1_objs = pt.builtin_scene(1)
+    c1_cam = pt.camera_new(width=256, height=256)
+    t0 = time.perf_counter()
+    orc.render(c1_cam, c1_objs, pt.default_params(spp=4), orc.F64, orc.RECURSIVE, threads=1)
+    c1_dt = time.perf_counter() - t0
     return {
         "value": round(samples / dt / 1e6, 4),
         "unit": "Msamples/s",
@@ -85,6 +91,8 @@ def cpu_baseline(pt, objs):
         "sample": f"C2 scene, {WIDTH}x{HEIGHT} camera, every {band_count}th row ({rows} rows), {spp} of {SPP} spp = "
                   f"{samples} samples in {dt:.2f} s wall; oracle f64 recursive (reference-shaped: linear scan, "
                   f"3 scans per vertex), {cores} threads over pixels ({avail} CPUs visible)",
+        "config0_single_thread": {"value": round(256 * 256 * 4 / c1_dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                                  "sample": f"C1 reference scene, 256x256, 4 spp = 262144 samples in {c1_dt:.2f} s"},
     }
 
 

@@ -227,3 +227,36 @@ def test_full_size_exact_mode_is_bit_identical_to_the_f32_oracle(pt, orc, gpu_ct
     assert len(bad) == 0, (label, len(bad), bad[:5].tolist())
     assert np.array_equal(rgba.cpu().numpy(), ref8)
     assert (st.vertices, st.shadow_rays, st.max_depth_reached) == (cnt["vertices"], cnt["shadow_rays"], cnt["max_depth"])
+
+
+def test_convergence_at_4096_spp_shows_no_bias(pt, orc, gpu_ctx):
+    """SURVEY 8(d) parity bar (iii): GPU f32 (default arithmetic) against the f64 reference-faithful oracle at
+    4096 spp on a 128 x 128 image of C2.  (1) Same sample indices: the two films differ only by f32 rounding and
+    rare branch flips -- far below the Monte-Carlo noise.  (2) Disjoint sample indices (spp_offset = 4096): the
+    GPU film is then an independent estimate; its difference to the oracle must look like noise -- image-mean
+    difference within 3 sigma, per-pixel z-scores with unit spread, no excess of > 3 sigma pixels.
+    The per-pixel sigma of a 4096-spp mean is estimated from eight independent 512-spp GPU renders."""
+    objs = pt.builtin_scene(2)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_new(width=128, height=128)
+    spp = 4096
+    ref, _, _ = orc.render(cam, objs, pt.default_params(spp=spp), F64, REC, THREADS)
+    ref = ref.mean(axis=-1)                                                    # grey value per pixel
+    same = gpu_ctx.render(cam, pt.default_params(spp=spp))[0].cpu().numpy().astype(np.float64).mean(axis=-1)
+    other = gpu_ctx.render(cam, pt.default_params(spp=spp, spp_offset=spp))[0].cpu().numpy().astype(np.float64).mean(axis=-1)
+    parts = np.stack([gpu_ctx.render(cam, pt.default_params(spp=512, spp_offset=2 * spp + 512 * k))[0].cpu().numpy()
+                      .astype(np.float64).mean(axis=-1) for k in range(8)])
+    sigma = parts.std(axis=0, ddof=1) / np.sqrt(8.0)                           # sigma of a 4096-spp pixel mean
+    lit = sigma > 0
+    assert lit.mean() > 0.95
+    # (1) same samples: rounding-level agreement
+    d_same = same - ref
+    assert abs(d_same.mean()) <= 1e-4 * ref.mean()
+    assert np.mean(np.abs(d_same[lit]) <= 0.5 * sigma[lit]) >= 0.995
+    # (2) independent samples: differences are noise, not bias
+    z = (other - ref)[lit] / (np.sqrt(2.0) * sigma[lit])
+    mean_sigma = np.sqrt(2.0 * (sigma[lit] ** 2).sum()) / lit.sum()            # sigma of the image-mean difference
+    assert abs((other - ref)[lit].mean()) <= 3.0 * mean_sigma, ((other - ref)[lit].mean(), mean_sigma)
+    spread = np.median(np.abs(z)) / 0.6745                                     # robust estimate of std(z), 1 for pure noise
+    assert 0.75 <= spread <= 1.35, spread
+    assert np.mean(np.abs(z) > 4.0) <= 0.01                                    # sigma is itself estimated from 8 parts: heavy tails
