@@ -29,3 +29,4 @@ if "c4bf" in which: run("C4 BVH", pt.builtin_scene(4, 10000), 1024, 1024, 256, r
 if "c1b" in which: run("C1 BVH", pt.builtin_scene(1), 1024, 1024, 64, accel=1)
 if "c2b" in which: run("C2 BVH", pt.builtin_scene(2), 1024, 1024, 64, accel=1)
 if "c6b" in which: run("100k spheres BVH", pt.builtin_scene(4, 100000), 1024, 1024, 64, accel=1)
+if "c5f" in which: run("C5 full (1024 spp) on one GPU", pt.builtin_scene(2), 3840, 2160, 1024, reps=1)
