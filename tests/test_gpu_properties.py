@@ -136,3 +136,29 @@ def test_progressive_preview_ends_bit_identical_to_one_shot(pt, gpu_ctx):
     seen = []
     gpu_ctx.render_progressive(cam, pt.default_params(spp=10), 3, lambda done, *_: seen.append(done) or done >= 6)
     assert seen == [3, 6]
+
+
+def test_maximum_sizes(pt, orc, gpu_ctx):
+    """The limits of the packed path state (row, x, sample-in-batch and depth are 16-bit fields): the widest and
+    the tallest legal tile and more samples per pixel than one batch can index, bit-exact against the f32 oracle;
+    one past the limit is a status code."""
+    objs = pt.builtin_scene(2)
+    gpu_ctx.upload(objs)
+    for (w, h, spp) in [(65535, 2, 1), (2, 65535, 1), (2, 2, 70001)]:
+        cam = pt.camera_new(width=w, height=h)
+        prm = pt.default_params(spp=spp, exact_math=1)
+        lin, rgba = gpu_ctx.render(cam, prm)
+        st = gpu_ctx.stats()
+        ref, ref8, cnt = orc.render(cam, objs, prm, orc.F32, orc.ITERATIVE, 16)
+        assert np.array_equal(lin.cpu().numpy(), ref.astype(np.float32)), (w, h, spp)
+        assert np.array_equal(rgba.cpu().numpy(), ref8) and st.vertices == cnt["vertices"]
+        if spp > 65535:
+            assert st.batches == 2                          # 65535 samples per pixel per batch at most
+    for (w, h) in [(65536, 2), (2, 65536)]:
+        with pytest.raises(pt._lib.PtError, match="65536"):
+            gpu_ctx.render(pt.camera_new(width=w, height=h), pt.default_params(spp=1))
+    # a taller image is fine as long as each tile has < 65536 rows
+    cam = pt.camera_new(width=2, height=70000)
+    lin, _ = gpu_ctx.render(cam, pt.default_params(spp=1, exact_math=1, band_rows=35000, band_index=1, band_count=2))
+    ref, _, _ = orc.render(cam, objs, pt.default_params(spp=1, band_rows=35000, band_index=1, band_count=2), orc.F32, orc.ITERATIVE, 16)
+    assert lin.shape[0] == 35000 and np.array_equal(lin.cpu().numpy(), ref.astype(np.float32))
