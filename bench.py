@@ -130,7 +130,7 @@ def main():
     import torch
     import torch.distributed as dist
     import pathtrace_amd as pt
-    from pathtrace_amd.dist import default_band_rows, gather_film
+    from pathtrace_amd.dist import FilmGather, default_band_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -170,13 +170,16 @@ def main():
     acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0,
            "p_vertices": 0, "p_ms": 0.0, "p_launches": 0}
 
+    # the single exchange step of the path: one gather of the framebuffer (f32 + RGBA8 packed) per step.  It is
+    # launched asynchronously, so the gather of step k runs (on the backend's stream) while step k + 1 renders; the
+    # last one is completed inside the timed region.
+    film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev) if world > 1 else None
+
     def step(record):
         ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         ctx.sync()
-        frame = frame8 = None
         if world > 1:
-            # the single exchange step of the path: one gather of the framebuffer (f32 + RGBA8 packed)
-            frame, frame8 = gather_film(lin.to(comm_dev), rgba.to(comm_dev), HEIGHT, band_rows, rank, world)
+            film_gather.start(lin.to(comm_dev), rgba.to(comm_dev))
         if record:
             st = ctx.stats()
             acc["vertices"] += st.vertices
@@ -187,19 +190,23 @@ def main():
             acc["p_vertices"] += st.primary_vertices
             acc["p_ms"] += st.primary_kernel_ms
             acc["p_launches"] += st.primary_launches
-        return frame, frame8
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    frame = frame8 = None
     for _ in range(args.warmup):
         step(False)
+    if world > 1:
+        film_gather.finish()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        frame, frame8 = step(True)
+        step(True)
+    if world > 1:
+        frame, frame8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -243,7 +250,7 @@ def main():
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
                 "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "
-                                                          f"ONE {args.backend} gather of the packed f32 + RGBA8 frame to rank 0 per step",
+                                                          f"ONE {args.backend} gather of the packed f32 + RGBA8 frame to rank 0 per step, overlapped with the next step's rendering",
             },
             "roofline": {
                 "kernel": ("k_paths_bvh<MIS, OVF=false>" if args.accel else

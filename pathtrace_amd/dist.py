@@ -48,7 +48,8 @@ class FilmGather:
     """The per-frame exchange with everything that does not change from frame to frame done once: row
     partition, padded send tile, receive buffer and the row permutation that puts the gathered band rows in
     image order.  Per frame: two pack copies, ONE dist.gather, one index_select, two unpack copies -- no Python
-    loop over rows, no host-to-device copy.
+    loop over rows, no host-to-device copy.  start()/finish() split the exchange so that the gather of frame k
+    overlaps the rendering of frame k + 1 (bench.py); calling the object does both at once.
 
     Both film planes travel together: the f32 linear plane [rows, W, 3] and the RGBA8 plane [rows, W, 4] are
     packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel)."""
@@ -60,6 +61,7 @@ class FilmGather:
         self.max_rows = max(len(r) for r in rows)
         self.send = torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device)
         self.recv = self.bufs = self.perm = None
+        self._work, self._pending, self._last = None, False, (None, None)
         if rank == dst:
             self.recv = torch.empty((world_size, self.max_rows, width, 16), dtype=torch.uint8, device=device)
             self.bufs = [self.recv[g] for g in range(world_size)]
@@ -69,21 +71,42 @@ class FilmGather:
                     perm[y] = g * self.max_rows + k
             self.perm = torch.tensor(perm, dtype=torch.int64).to(device)
 
-    def __call__(self, lin, rgba):
-        """(linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`, (None, None) elsewhere."""
+    def start(self, lin, rgba):
+        """Pack this rank's tile and launch the gather without waiting for it (async_op): the collective runs
+        on the backend's own stream / thread while the caller renders the next frame.  A previous gather still in
+        flight is completed first (its frame is then available from finish())."""
+        if self._work is not None or self._pending:
+            self._last = self.finish()
         n, w = self.my_rows, self.width
         assert lin.shape[0] == n and rgba.shape[0] == n, (lin.shape, rgba.shape, n)
         self.send[:n, :, :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(n, w, 12)
         self.send[:n, :, 12:] = rgba
-        if self.world == 1:
-            frame = self.send.index_select(0, self.perm)
-        else:
-            dist.gather(self.send, gather_list=self.bufs, dst=self.dst, group=self.group)
-            if self.rank != self.dst:
-                return None, None
-            frame = self.recv.view(self.world * self.max_rows, w, 16).index_select(0, self.perm)
+        if self.world > 1:
+            self._work = dist.gather(self.send, gather_list=self.bufs, dst=self.dst, group=self.group, async_op=True)
+        self._pending = True
+
+    def finish(self):
+        """Wait for the gather launched by start() and return (linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`,
+        (None, None) elsewhere.  Without a pending gather: the frame of the last one completed by start()."""
+        if not self._pending:
+            last, self._last = self._last, (None, None)
+            return last
+        if self._work is not None:
+            self._work.wait()          # nccl: the current stream waits for the collective; gloo: the host does
+            self._work = None
+        self._pending = False
+        if self.rank != self.dst:
+            return None, None
+        w = self.width
+        src = self.send if self.world == 1 else self.recv.view(self.world * self.max_rows, w, 16)
+        frame = src.index_select(0, self.perm)
         lin_full = frame[..., :12].contiguous().reshape(-1).view(torch.float32).reshape(self.height, w, 3)
         return lin_full, frame[..., 12:].contiguous()
+
+    def __call__(self, lin, rgba):
+        """start() + finish(): the blocking form."""
+        self.start(lin, rgba)
+        return self.finish()
 
 
 _plans = {}

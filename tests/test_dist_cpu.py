@@ -42,6 +42,23 @@ def _worker(rank, world, port, H, W, band_rows, out_path):
         assert torch.equal(pf, frame) and torch.equal(p8, frame8)
     else:
         assert pf is None and p8 is None
+    # the pipelined form of bench.py: start() of frame k + 1 completes the gather of frame k; frames differ per step
+    from pathtrace_amd.dist import FilmGather
+    fg = FilmGather(H, W, band_rows, rank, world, torch.device("cpu"))
+    lin_t, rgba_t = torch.from_numpy(lin.astype(np.float32)), torch.from_numpy(rgba)
+    got = []
+    for k in range(3):
+        fg.start(lin_t + float(k), (rgba_t + k).to(torch.uint8))
+        if k:
+            got.append(fg._last)                     # frame k - 1, completed by this start()
+            fg._last = (None, None)
+    got.append(fg.finish())
+    assert fg.finish() == (None, None)               # nothing pending any more
+    for k, (gl, g8) in enumerate(got):
+        if rank == 0:
+            assert torch.equal(gl, frame + float(k)) and torch.equal(g8, (frame8 + k).to(torch.uint8)), k
+        else:
+            assert gl is None and g8 is None
     dist.barrier()
     if rank == 0:
         np.savez(out_path, lin=frame.numpy(), rgba=frame8.numpy())

@@ -15,6 +15,13 @@ send = (torch.rand((128, 1024, 16), device=dev) * 255).to(torch.uint8)
 recv = torch.empty((1, 128, 1024, 16), dtype=torch.uint8, device=dev)
 dist.gather(send, gather_list=[recv[0]], dst=0)
 assert torch.equal(recv[0], send)
+# ... launched asynchronously and completed later (FilmGather.start / finish), twice in a row on the same buffers
+for k in range(2):
+    send.add_(1)
+    work = dist.gather(send, gather_list=[recv[0]], dst=0, async_op=True)
+    busy = torch.rand((2048, 2048), device=dev) @ torch.rand((2048, 2048), device=dev)     # other work on the current stream
+    work.wait()
+    assert torch.equal(recv[0], send), k
 x = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(x, op=dist.ReduceOp.MAX); assert x.item() == 1.5
 y = torch.tensor([3.0, 4.0], dtype=torch.float64, device=dev); dist.all_reduce(y, op=dist.ReduceOp.SUM); assert y.tolist() == [3.0, 4.0]
 dist.barrier()
