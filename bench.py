@@ -254,7 +254,7 @@ def main():
             },
             "roofline": {
                 "kernel": ("k_paths_bvh<MIS, OVF=false>" if args.accel else
-                           ("k_paths<kModeLds, MIS, OVF=false>" if len(objs) <= 128 else "k_paths<kModeTiled, MIS, OVF=false>")) +
+                           ("k_paths<kModeLds, MIS, OVF=false, DIFFUSE>" if len(objs) <= 128 else "k_paths<kModeTiled, MIS, OVF=false>")) +
                           ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
                           "over their sparse tails), rank 0",
                 "bound": "hbm",

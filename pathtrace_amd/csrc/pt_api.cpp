@@ -340,6 +340,9 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     }
     c->view.scan_f4 = (uint32_t)scan.size();
     c->view.n_runs = (uint32_t)runs.size(); c->view.n_objs = n; c->view.n_lights = (uint32_t)lights.size();
+    c->view.diffuse_only = 1u;
+    for (uint32_t i = 0; i < n; ++i)
+        if (objs[i].mat_tag != PT_MAT_LAMBERT && objs[i].mat_tag != PT_MAT_EMISSIVE) c->view.diffuse_only = 0u;
     c->view.bvh = ptk::BvhView{};
     c->has_bvh = false;
     c->h_shape.assign(shape.begin(), shape.begin() + 3 * (size_t)n);

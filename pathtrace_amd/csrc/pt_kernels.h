@@ -37,6 +37,7 @@ struct SceneView {
     uint32_t blob_f4;        // float4 count of `blob` (0 for larger scenes)
     uint32_t scan_f4;        // float4 count of `scan`
     uint32_t n_runs, n_objs, n_lights;
+    uint32_t diffuse_only;   // every material is Lambertian or emissive: kernels without the GGX / OrenNayar code
     BvhView bvh;             // valid only for launches with accel != 0
 };
 
