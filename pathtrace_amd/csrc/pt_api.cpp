@@ -55,10 +55,13 @@ template <class T> struct DevBuf {
 };
 
 constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
-// Default number of workgroups: about 1024 paths (64 KiB of queue) per wave.  Measured at 67 M paths:
-// 2048 workgroups 11.6 ms, 8192 10.7, 16384 10.2 (best), 32768 10.6, 65536 11.7.  At ~1024 paths per
-// wave the segments of the 4096 resident waves (256 MB) still fit the 256 MiB Infinity Cache and the
-// dispatcher balances the end of the launch; smaller segments pay more low-occupancy tail passes.
+// Default number of workgroups.  What matters is that the queue segments of the RESIDENT waves fit the 256 MiB
+// Infinity Cache (and that the dispatcher has enough workgroups to balance the end of the launch; much smaller
+// segments pay more low-occupancy tail passes).  Scene in LDS, 6 waves/SIMD = 6144 resident waves: ~672 paths
+// (42 KiB of queue) per wave -- measured at 67 M paths: 8192 workgroups 10.31 ms, 12288 10.12, 16384 9.86,
+// 24576 9.61 (best), 32768 9.69.  Tiled scan and BVH kernels (4-5 waves/SIMD): ~1024 paths per wave (measured at
+// 4 waves/SIMD: 2048 workgroups 11.6 ms, 8192 10.7, 16384 10.2 (best), 32768 10.6, 65536 11.7).
+constexpr uint32_t kPathsPerWaveLds = 672;
 constexpr uint32_t kPathsPerWave = 1024;
 constexpr uint32_t kMinGrid = 256 * 8;         // at least two rounds of 4 resident workgroups per CU
 // Tail hand-off: in launches of more than kExportMinPaths paths a wave whose segment falls below one chunk
@@ -388,8 +391,9 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const uint32_t grid_env = prm->workgroups;
     const uint32_t chunks_max = (uint32_t)((n_paths_max + 63) / 64);
     uint32_t grid = grid_env;
+    const uint32_t paths_per_wave = (c->view.n_objs <= ptk::kSmallObjs && !prm->accel) ? kPathsPerWaveLds : kPathsPerWave;
     if (!grid) {
-        const uint64_t want = (n_paths_max + (uint64_t)kPathsPerWave * kWavesPerBlock - 1) / ((uint64_t)kPathsPerWave * kWavesPerBlock);
+        const uint64_t want = (n_paths_max + (uint64_t)paths_per_wave * kWavesPerBlock - 1) / ((uint64_t)paths_per_wave * kWavesPerBlock);
         grid = (uint32_t)std::max<uint64_t>(want, kMinGrid);
     }
     grid = std::min<uint32_t>(grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -466,7 +470,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             const uint32_t chunks = (n_level + 63u) / 64u;
             uint32_t g = grid;
             if (level > 0) {
-                const uint64_t want = ((uint64_t)n_level + (uint64_t)kPathsPerWave * kWavesPerBlock - 1) / ((uint64_t)kPathsPerWave * kWavesPerBlock);
+                const uint64_t want = ((uint64_t)n_level + (uint64_t)paths_per_wave * kWavesPerBlock - 1) / ((uint64_t)paths_per_wave * kWavesPerBlock);
                 g = (uint32_t)std::max<uint64_t>(want, kMinGrid);
                 g = std::min<uint32_t>(g, (chunks + kWavesPerBlock - 1) / kWavesPerBlock);
             }

@@ -303,7 +303,7 @@ PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_
 
 // (id, t) = closest hit of the path ray, id < 0: miss.  Credits an emitter hit into p.L and samples the light point.
 // DIFFUSE: the scene has Lambertian and emissive materials only (decided at pt_scene_upload); the GGX and
-// OrenNayar code is then compiled out of the kernel (same results; smaller code, fewer registers: C2 +3 %).
+// OrenNayar code is then compiled out of the kernel (same results; smaller code, no spills at 6 waves/SIMD: C2 +2 %).
 template <bool MIS, bool DIFFUSE>
 PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, float t, uint32_t sample, uint32_t py,
                          Vertex& v) {
@@ -419,19 +419,23 @@ PT_DEV bool vertex_end(PathState& p, const Vertex& v, bool visible, uint32_t sam
 // (Camera::get_ray_with_offset), so every segment samples the whole image and the
 // waves finish together.
 //
-// Memory pipeline of one iteration: the NEXT chunk's state is requested at the top
-// (4 x 16 B per lane in flight during the whole vertex computation) and consumed
-// just BEFORE this iteration's stores, so the only vector-memory wait of the loop
-// sits behind ~5000 cycles of work and never behind a store.  With a SMALL scene
-// nothing else in the loop touches global memory.
-#ifndef PT_BOUNCE_WAVES
-#define PT_BOUNCE_WAVES 4      // minimum waves per SIMD the register allocator must leave room for
+// Memory access of one iteration: the chunk's state is loaded at the top (4 x 16 B per lane, coalesced) and the
+// survivors are stored at the bottom; with a scene in LDS nothing else touches global memory.  (An earlier version
+// requested the NEXT chunk's state one iteration ahead.  The register allocator had to keep those 16 registers
+// somewhere for a whole vertex, placed the copies -- and so the wait -- right after the loads anyway, and the
+// pressure cost a wave of occupancy: without it the kernel needs 80-90 VGPRs instead of 115-128 and runs 6 waves
+// per SIMD, C2 10.14 -> 9.78 ms, C1 16.1 -> 14.9 ms.)
+// minimum waves per SIMD the register allocator must leave room for.  Scene in LDS: 80 VGPRs (the DIFFUSE variant
+// without spilling, the generic one with 8 spilled dwords); measured 4 / 5 / 6 / 7 waves: C2 10.14 / 9.84 / 9.78 /
+// 10.04 ms, C1 16.1 / 15.2 / 14.9 ms.  Tiled scan: 125 VGPRs, 4 waves.
+#ifndef PT_BOUNCE_WAVES_LDS
+#define PT_BOUNCE_WAVES_LDS 6
 #endif
-#ifndef PT_BOUNCE_WAVES_DIFFUSE
-#define PT_BOUNCE_WAVES_DIFFUSE 5   // without the GGX code 96 registers + 11 spilled dwords: measured 3 % faster than 4 waves
+#ifndef PT_BOUNCE_WAVES_TILED
+#define PT_BOUNCE_WAVES_TILED 4
 #endif
 template <int MODE, bool MIS, bool OVF, bool DIFFUSE>   // OVF: continuation launch, pass 0 reads the overflow queue
-__global__ void __launch_bounds__(kBlock, DIFFUSE && MODE == kModeLds ? PT_BOUNCE_WAVES_DIFFUSE : PT_BOUNCE_WAVES)
+__global__ void __launch_bounds__(kBlock, MODE == kModeLds ? PT_BOUNCE_WAVES_LDS : PT_BOUNCE_WAVES_TILED)
 k_paths(BounceArgs a) {
     // SMALL = "the waves of a workgroup are independent" (no barrier inside the scan): wave-private queue
     // segments.  The tiled scan ties the four waves of a workgroup together.  (kModeBvh: k_paths_bvh.)
@@ -463,14 +467,8 @@ k_paths(BounceArgs a) {
     if (n_iter == 0u) break;               // SMALL: this wave is done; tiled: the whole workgroup is (uniform)
     uint32_t out_n = 0;                    // wave-uniform: survivors written so far in this pass
 
-    // state of the next chunk, in flight
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     const uint32_t lane_off = SMALL ? lane : wib * 64u + lane;   // position inside a chunk (64 or 256 slots)
     const uint32_t chunk_slots = SMALL ? 64u : kBlock;
-    if (!first && lane_off < n_in) {
-        const uint32_t s0 = seg_base + lane_off;
-        n0 = a.q.q[0][s0]; n1 = a.q.q[1][s0]; n2 = a.q.q[2][s0]; n3 = a.q.q[3][s0];
-    }
 
     for (uint32_t it = 0; it < n_iter; ++it) {
         bool active;
@@ -493,13 +491,9 @@ k_paths(BounceArgs a) {
             }
         } else {
             active = it * chunk_slots + lane_off < n_in;
-            p = unpack_state(n0, n1, n2, n3);
-            if (!active) { p.o = parked_origin(); p.d = parked_dir(); }
-            // request the next chunk now; it is consumed just before this iteration's stores
-            const uint32_t nxt = (it + 1u) * chunk_slots + lane_off;
-            if (nxt < n_in) {
-                const uint32_t s1 = seg_base + nxt;
-                n0 = a.q.q[0][s1]; n1 = a.q.q[1][s1]; n2 = a.q.q[2][s1]; n3 = a.q.q[3][s1];
+            if (active) {
+                const uint32_t s0 = seg_base + it * chunk_slots + lane_off;
+                p = unpack_state(a.q.q[0][s0], a.q.q[1][s0], a.q.q[2][s0], a.q.q[3][s0]);
             }
         }
         const uint32_t py = image_row(a.tile, p.yl);     // key of the path's RNG stream = (x, y), main.rs:51
@@ -540,14 +534,6 @@ k_paths(BounceArgs a) {
             }
         }
         const bool alive = vertex_end<MIS, DIFFUSE>(p, v, visible, sample, py, a.min_depth, a.max_depth);
-
-        // ---- the next chunk must have landed before anything is stored (in-place queue)
-        if (!first) {
-            asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z),
-                         "+v"(n1.w));
-            asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y), "+v"(n3.z),
-                         "+v"(n3.w));
-        }
 
         // ---- retire, or compact in place into the wave's own segment
         if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
