@@ -427,12 +427,13 @@ PT_DEV bool vertex_end(PathState& p, const Vertex& v, bool visible, uint32_t sam
 // per SIMD, C2 10.14 -> 9.78 ms, C1 16.1 -> 14.9 ms.)
 // minimum waves per SIMD the register allocator must leave room for.  Scene in LDS: 80 VGPRs (the DIFFUSE variant
 // without spilling, the generic one with 8 spilled dwords); measured 4 / 5 / 6 / 7 waves: C2 10.14 / 9.84 / 9.78 /
-// 10.04 ms, C1 16.1 / 15.2 / 14.9 ms.  Tiled scan: 125 VGPRs, 4 waves.
+// 10.04 ms, C1 16.1 / 15.2 / 14.9 ms.  Tiled scan: 5 waves (96 VGPRs + 21 spilled dwords, 30 KiB tile so that five
+// workgroups fit a CU): C4 1214 -> 1106 ms; 6 waves with a 24 KiB tile: the same.
 #ifndef PT_BOUNCE_WAVES_LDS
 #define PT_BOUNCE_WAVES_LDS 6
 #endif
 #ifndef PT_BOUNCE_WAVES_TILED
-#define PT_BOUNCE_WAVES_TILED 4
+#define PT_BOUNCE_WAVES_TILED 5
 #endif
 template <int MODE, bool MIS, bool OVF, bool DIFFUSE>   // OVF: continuation launch, pass 0 reads the overflow queue
 __global__ void __launch_bounds__(kBlock, MODE == kModeLds ? PT_BOUNCE_WAVES_LDS : PT_BOUNCE_WAVES_TILED)
