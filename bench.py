@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
                          "goes through host memory); the driver's runs use nccl (RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one rank: still initialise the process group and run every collective of the N > 1 path "
+                         "(rehearsal of that code over real RCCL on a one-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -142,8 +145,10 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    multi = world > 1 or args.force_dist        # run the distributed code path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -157,7 +162,7 @@ def main():
     objs = pt.builtin_scene(scene_id, scene_arg)
     cam = pt.camera_new(width=WIDTH, height=HEIGHT)
     spp = SPP * world
-    band_rows = default_band_rows(HEIGHT, world) if world > 1 else 0
+    band_rows = default_band_rows(HEIGHT, world) if multi else 0
     prm = pt.default_params(spp=spp, band_rows=band_rows, band_index=rank, band_count=world, profile=1,
                             max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
     ctx = pt.Context(dev_index)
@@ -173,12 +178,12 @@ def main():
     # the single exchange step of the path: one gather of the framebuffer (f32 + RGBA8 packed) per step.  It is
     # launched asynchronously, so the gather of step k runs (on the backend's stream) while step k + 1 renders; the
     # last one is completed inside the timed region.
-    film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev) if world > 1 else None
+    film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev, always_collective=True) if multi else None
 
     def step(record):
         ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         ctx.sync()
-        if world > 1:
+        if multi:
             film_gather.start(lin.to(comm_dev), rgba.to(comm_dev))
         if record:
             st = ctx.stats()
@@ -192,25 +197,25 @@ def main():
             acc["p_launches"] += st.primary_launches
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     frame = frame8 = None
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if multi:
         film_gather.finish()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if world > 1:
+    if multi:
         frame, frame8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -221,8 +226,10 @@ def main():
         job_samples = float(acc["samples"])
 
     if rank == 0:
-        if world > 1:
+        if multi:
             assert frame is not None and tuple(frame.shape) == (HEIGHT, WIDTH, 3) and torch.isfinite(frame).all()
+            if world == 1:
+                assert torch.equal(frame, lin) and torch.equal(frame8, rgba)     # --force-dist: the gathered frame is the tile
         else:
             assert torch.isfinite(lin).all()
         # the dominant kernel = the level-0 launch of each batch (camera rays + every bounce until its waves hand
@@ -274,7 +281,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pt, objs)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

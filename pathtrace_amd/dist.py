@@ -54,7 +54,7 @@ class FilmGather:
     Both film planes travel together: the f32 linear plane [rows, W, 3] and the RGBA8 plane [rows, W, 4] are
     packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel)."""
 
-    def __init__(self, height, width, band_rows, rank, world_size, device, group=None, dst=0):
+    def __init__(self, height, width, band_rows, rank, world_size, device, group=None, dst=0, always_collective=False):
         rows = [tile_row_indices(height, band_rows, g, world_size) for g in range(world_size)]
         self.height, self.width, self.rank, self.world, self.group, self.dst = height, width, rank, world_size, group, dst
         self.my_rows = len(rows[rank])
@@ -62,6 +62,9 @@ class FilmGather:
         self.send = torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device)
         self.recv = self.bufs = self.perm = None
         self._work, self._pending, self._last = None, False, (None, None)
+        # world_size 1 needs no exchange; always_collective issues the gather anyway (bench.py --force-dist: the whole
+        # N > 1 code path over the real backend on a one-GPU box)
+        self._collective = world_size > 1 or always_collective
         if rank == dst:
             self.recv = torch.empty((world_size, self.max_rows, width, 16), dtype=torch.uint8, device=device)
             self.bufs = [self.recv[g] for g in range(world_size)]
@@ -81,7 +84,7 @@ class FilmGather:
         assert lin.shape[0] == n and rgba.shape[0] == n, (lin.shape, rgba.shape, n)
         self.send[:n, :, :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(n, w, 12)
         self.send[:n, :, 12:] = rgba
-        if self.world > 1:
+        if self._collective:
             self._work = dist.gather(self.send, gather_list=self.bufs, dst=self.dst, group=self.group, async_op=True)
         self._pending = True
 
@@ -98,7 +101,7 @@ class FilmGather:
         if self.rank != self.dst:
             return None, None
         w = self.width
-        src = self.send if self.world == 1 else self.recv.view(self.world * self.max_rows, w, 16)
+        src = self.recv.view(self.world * self.max_rows, w, 16) if self._collective else self.send
         frame = src.index_select(0, self.perm)
         lin_full = frame[..., :12].contiguous().reshape(-1).view(torch.float32).reshape(self.height, w, 3)
         return lin_full, frame[..., 12:].contiguous()
