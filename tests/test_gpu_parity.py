@@ -206,16 +206,17 @@ def test_error_behaviour(pt, gpu_ctx):
     fresh.close()
 
 
-@pytest.mark.parametrize("scene,label", [(2, "C2"), (1, "C1")])
-def test_full_size_exact_mode_is_bit_identical_to_the_f32_oracle(pt, orc, gpu_ctx, scene, label):
-    """BASELINE's headline size -- 1024^2, 64 spp, 6.7e7 samples, ~3e8 path vertices -- in exact arithmetic against
+@pytest.mark.parametrize("scene,label,w,h,spp,integrator", [(2, "C2", 1024, 1024, 64, 0), (1, "C1", 1024, 1024, 64, 0),
+                                                          (2, "C5 size", 3840, 2160, 8, 0), (1, "C1 BRDF-only", 1024, 1024, 32, 1)])
+def test_full_size_exact_mode_is_bit_identical_to_the_f32_oracle(pt, orc, gpu_ctx, scene, label, w, h, spp, integrator):
+    """BASELINE's sizes -- 1024^2 x 64 spp (6.7e7 samples, ~3e8 path vertices) and C5's 3840 x 2160 -- in exact arithmetic against
     the f32 oracle: every pixel of both film planes and every counter.  Events of probability 1e-8 per vertex
     (empty shadow intervals, paths trapped by total internal reflection to depth 50, roulette at the depth limit,
     NaNs) occur a few times at this size and not at 256^2 x 4."""
     import time
     objs = pt.builtin_scene(scene)
-    cam = pt.camera_new(width=1024, height=1024)
-    prm = pt.default_params(spp=64, exact_math=1)
+    cam = pt.camera_new(width=w, height=h)
+    prm = pt.default_params(spp=spp, exact_math=1, integrator=integrator)
     gpu_ctx.upload(objs)
     lin, rgba = gpu_ctx.render(cam, prm)
     st = gpu_ctx.stats()
