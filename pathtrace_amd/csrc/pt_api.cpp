@@ -388,6 +388,10 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
 
     // Queue segments: one per wave of the (fixed) bounce grid; bounce 0 deals 64-path
     // chunks round-robin, so a segment holds at most ceil(chunks / waves) chunks.
+    // a wave hands its segment over when fewer paths than this are left (measured 32 ... 256: no difference beyond
+    // noise on C1 and C2 at ~672 paths per wave; one chunk it is)
+    uint32_t export_small = 64u;
+    if (const char* e = std::getenv("PT_EXPORT_BELOW")) export_small = (uint32_t)std::min(256, std::max(1, std::atoi(e)));   // tuning knob
     const uint32_t grid_env = prm->workgroups;
     const uint32_t chunks_max = (uint32_t)((n_paths_max + 63) / 64);
     uint32_t grid = grid_env;
@@ -403,9 +407,10 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const bool hand_off = true;
     const bool small_scene = c->view.n_objs <= ptk::kSmallObjs || prm->accel;     // the tiled scan exports per workgroup (< 256 paths)
     const uint32_t nw_cont = std::max(nw, kMinGrid * kWavesPerBlock);    // waves of any continuation launch
-    const size_t ovf_slots = (size_t)nw_cont * 64u;                      // a wave exports < 64 paths (a workgroup < 256)
-    // level 0 needs nw*seg_cap slots; a continuation launch of n <= nw*63 paths needs <= n + 64 + nw_cont*64
-    const size_t q_slots = std::max((size_t)nw * seg_cap, (size_t)nw * 63u + 64u + (size_t)nw_cont * 64u);
+    const uint32_t export_max = std::max(export_small, ptk::kBlock);      // a wave exports < export_small paths, a tiled workgroup < 256
+    const size_t ovf_slots = (size_t)nw_cont * export_max;
+    // level 0 needs nw*seg_cap slots; a continuation launch of n < nw*export_max paths needs <= n + 64 + nw_cont*64
+    const size_t q_slots = std::max((size_t)nw * seg_cap, (size_t)nw * export_max + 64u + (size_t)nw_cont * 64u);
 
     int rc;
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
@@ -478,7 +483,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             a.n_first = n_level;
             a.seg_cap = ((chunks + nw_l - 1) / nw_l) * 64u;
             a.src_mode = level > 0 ? 1u : 0u;
-            a.export_below = (hand_off && n_level > kExportMinPaths) ? (small_scene ? 64u : ptk::kBlock) : 1u;
+            a.export_below = (hand_off && n_level > kExportMinPaths) ? (small_scene ? export_small : ptk::kBlock) : 1u;
             for (int k = 0; k < 4; ++k) {
                 a.ovf_out.q[k] = hand_off ? c->ovf[level & 1][k].p : nullptr;
                 a.ovf_in.q[k] = hand_off ? c->ovf[(level + 1) & 1][k].p : nullptr;

@@ -566,9 +566,9 @@ k_paths(BounceArgs a) {
         uint32_t base = 0;
         if (lane == 0u) base = atomicAdd(a.ovf_out_count, n_in);
         base = __shfl(base, 0);
-        if (lane < n_in) {
+        for (uint32_t j = lane; j < n_in; j += 64u) {
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + lane]; a.ovf_out.q[k][base + lane] = t; }
+            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + j]; a.ovf_out.q[k][base + j] = t; }
         }
     }
     if (!SMALL && n_in != 0u) {            // tiled: the workgroup exports its shared segment (< 256 paths)
@@ -843,9 +843,9 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
         uint32_t base = 0;
         if (lane == 0u) base = atomicAdd(a.ovf_out_count, n_in);
         base = __shfl(base, 0);
-        if (lane < n_in) {
+        for (uint32_t j = lane; j < n_in; j += 64u) {
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + lane]; a.ovf_out.q[k][base + lane] = t; }
+            for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + j]; a.ovf_out.q[k][base + j] = t; }
         }
     }
     if (lane == 0u) {
