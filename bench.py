@@ -114,8 +114,8 @@ def pmc_traffic(world, workload="c2"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0, help="PtRenderParams.max_paths_in_flight (0 = default)")
     ap.add_argument("--workgroups", type=int, default=0)
