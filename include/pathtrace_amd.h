@@ -180,7 +180,9 @@ int pt_scene_upload(PtContext* ctx, const PtObject* objs, uint32_t n_objs);
  *                 draw(), src/world.rs:322-341); may be NULL.
  * Work is enqueued on the context's stream; the call returns once the last launch is
  * enqueued (it synchronises internally once per sample batch, where the tail of the
- * level-0 launch is handed to a continuation launch).  pt_sync() waits for the rest.   */
+ * level-0 launch is handed to a continuation launch).  Renders of several sample batches
+ * also use a second, context-owned stream for those tails; the context's stream waits
+ * for it at the end, so everything is complete when that stream is.  pt_sync() waits.   */
 int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
                      float* d_linear_rgb, uint8_t* d_rgba8);
 int pt_sync(PtContext* ctx);

@@ -96,8 +96,14 @@ struct PtContext {
     // wavefront state
     DevBuf<float4> queue[4];
     DevBuf<float4> bvh_aux, bvh_sray[2];   // accel = 1: per-slot scratch of the staged passes (k_paths_bvh)
-    DevBuf<float4> ovf[2][4];         // overflow queues of the tail hand-off (ping-pong between launches)
-    DevBuf<uint32_t> ovf_count;       // [2]
+    DevBuf<float4> ovf[2][2][4];      // overflow queues of the tail hand-off: [batch parity][level parity][plane]
+    DevBuf<uint32_t> ovf_count;       // [batch parity][level parity]
+    // multi-batch renders: the continuation launches and the film resolve of batch k run on side_stream while the
+    // level-0 launch of batch k + 1 runs on the caller's stream (their own queue and a second sample buffer)
+    hipStream_t side_stream = nullptr;
+    DevBuf<float4> cqueue[4];
+    DevBuf<float4> lsamp2;
+    hipEvent_t ev_l0[2] = {nullptr, nullptr}, ev_resolved[2] = {nullptr, nullptr};
     uint32_t* h_ovf = nullptr;        // pinned read-back of one counter
     DevBuf<float4> lsamp;
     DevBuf<unsigned long long> dstats;
@@ -229,6 +235,16 @@ int pt_context_create(int device, PtContext** out) {
         return fail(PT_ERR_HIP, "hipStreamCreateWithFlags failed");
     }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "hipStreamCreateWithFlags failed");
+    }
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&c->ev_l0[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_resolved[k], hipEventDisableTiming) != hipSuccess) {
+            delete c;
+            return fail(PT_ERR_HIP, "hipEventCreate failed");
+        }
     if (hipHostMalloc((void**)&c->h_dstats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_ovf, 4 * sizeof(uint32_t)) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
@@ -243,11 +259,19 @@ int pt_context_destroy(PtContext* c) {
     if (!c) return PT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release();
     c->bvh_aux.release(); c->bvh_sray[0].release(); c->bvh_sray[1].release();
     for (auto& b : c->queue) b.release();
-    for (auto& q : c->ovf) for (auto& b : q) b.release();
+    for (auto& par : c->ovf) for (auto& q : par) for (auto& b : q) b.release();
+    for (auto& b : c->cqueue) b.release();
+    c->lsamp2.release();
+    for (int k = 0; k < 2; ++k) {
+        if (c->ev_l0[k]) (void)hipEventDestroy(c->ev_l0[k]);
+        if (c->ev_resolved[k]) (void)hipEventDestroy(c->ev_resolved[k]);
+    }
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->ovf_count.release();
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     c->lsamp.release(); c->dstats.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
@@ -410,7 +434,10 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const uint32_t export_max = std::max(export_small, ptk::kBlock);      // a wave exports < export_small paths, a tiled workgroup < 256
     const size_t ovf_slots = (size_t)nw_cont * export_max;
     // level 0 needs nw*seg_cap slots; a continuation launch of n < nw*export_max paths needs <= n + 64 + nw_cont*64
-    const size_t q_slots = std::max((size_t)nw * seg_cap, (size_t)nw * export_max + 64u + (size_t)nw_cont * 64u);
+    const size_t q_slots_cont = (size_t)nw * export_max + 64u + (size_t)nw_cont * 64u;
+    const size_t q_slots = std::max((size_t)nw * seg_cap, q_slots_cont);
+    // Multi-batch renders overlap the tail of batch k (continuation launches, resolve) with the body of batch k + 1
+    const bool overlap = n_batches > 1 && !prm->accel;
 
     int rc;
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
@@ -420,19 +447,22 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
                        (rc = c->bvh_sray[1].ensure(q_slots))))
         return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
-    if ((rc = c->ovf_count.ensure(2))) return rc;
+    if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
+    if (overlap)
+        for (int k = 0; k < 4; ++k)
+            if ((rc = c->cqueue[k].ensure(q_slots_cont))) return rc;
+    if ((rc = c->ovf_count.ensure(4))) return rc;
     if (hand_off)
-        for (int b = 0; b < 2; ++b)
-            for (int k = 0; k < 4; ++k)
-                if ((rc = c->ovf[b][k].ensure(ovf_slots))) return rc;
+        for (int par = 0; par < (overlap ? 2 : 1); ++par)
+            for (int b = 0; b < 2; ++b)
+                for (int k = 0; k < 4; ++k)
+                    if ((rc = c->ovf[par][b][k].ensure(ovf_slots))) return rc;
     if ((rc = c->dstats.ensure(8))) return rc;
     if ((n_batches > 1 || c->prog_load || c->prog_store) && (rc = c->film.ensure((size_t)np * 3))) return rc;
 
     ptk::BounceArgs a{};
-    for (int k = 0; k < 4; ++k) a.q.q[k] = c->queue[k].p;
     a.seg_cap = seg_cap;
     a.aux = c->bvh_aux.p; a.sray0 = c->bvh_sray[0].p; a.sray1 = c->bvh_sray[1].p;
-    a.lsamp = c->lsamp.p;
     a.stats = c->dstats.p;
     {   // tile row -> image row without a table (ptk::TileMap)
         const uint32_t br = prm->band_rows ? prm->band_rows : cam->height;
@@ -464,14 +494,25 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     uint32_t launches = 0;
     c->primary_events.clear();
 
+    hipStream_t side = overlap ? c->side_stream : st;
+    if (overlap) {      // the side stream starts after whatever the caller's stream holds so far (previous renders, film state)
+        HIP_TRY(hipEventRecord(c->ev_l0[0], st));
+        HIP_TRY(hipStreamWaitEvent(side, c->ev_l0[0], 0));
+    }
     for (uint32_t batch = 0; batch < n_batches; ++batch) {
         const uint32_t s0 = batch * nb_max;
         const uint32_t nb = std::min(nb_max, prm->spp - s0);
+        const int par = overlap ? (int)(batch & 1u) : 0;          // buffers of this batch
+        float4* const lsamp_b = par ? c->lsamp2.p : c->lsamp.p;
         a.s_base = prm->spp_offset + s0;
+        a.lsamp = lsamp_b;
+        // batch k reuses the sample buffer and overflow queues of batch k - 2: wait until its tail is through
+        if (overlap && batch >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[par], 0));
         // Level 0 traces the batch's paths (every bounce, see k_paths); waves hand their sparse tails to the
         // overflow queue, which the next level consumes densely, until a level is small enough to finish alone.
         uint32_t n_level = np * nb;
         for (uint32_t level = 0; n_level != 0u; ++level) {
+            hipStream_t ls = level == 0 ? st : side;
             const uint32_t chunks = (n_level + 63u) / 64u;
             uint32_t g = grid;
             if (level > 0) {
@@ -485,30 +526,35 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             a.src_mode = level > 0 ? 1u : 0u;
             a.export_below = (hand_off && n_level > kExportMinPaths) ? (small_scene ? export_small : ptk::kBlock) : 1u;
             for (int k = 0; k < 4; ++k) {
-                a.ovf_out.q[k] = hand_off ? c->ovf[level & 1][k].p : nullptr;
-                a.ovf_in.q[k] = hand_off ? c->ovf[(level + 1) & 1][k].p : nullptr;
+                a.q.q[k] = (overlap && level > 0) ? c->cqueue[k].p : c->queue[k].p;
+                a.ovf_out.q[k] = hand_off ? c->ovf[par][level & 1][k].p : nullptr;
+                a.ovf_in.q[k] = hand_off ? c->ovf[par][(level + 1) & 1][k].p : nullptr;
             }
-            a.ovf_out_count = c->ovf_count.p + (level & 1);
-            if (a.export_below > 1u) HIP_TRY(hipMemsetAsync(a.ovf_out_count, 0, sizeof(uint32_t), st));
+            a.ovf_out_count = c->ovf_count.p + 2 * par + (level & 1);
+            if (a.export_below > 1u) HIP_TRY(hipMemsetAsync(a.ovf_out_count, 0, sizeof(uint32_t), ls));
             if (profile) {
                 if ((rc = ensure_events(c, 2 * (size_t)(launches + 1)))) return rc;
-                HIP_TRY(hipEventRecord(c->ev_pool[2 * launches], st));
+                HIP_TRY(hipEventRecord(c->ev_pool[2 * launches], ls));
             }
-            if (prm->exact_math) ptk::launch_paths_exact(a, g, st);
-            else ptk::launch_paths_fast(a, g, st);
-            if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * launches + 1], st));
+            if (prm->exact_math) ptk::launch_paths_exact(a, g, ls);
+            else ptk::launch_paths_fast(a, g, ls);
+            if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * launches + 1], ls));
             HIP_TRY(hipGetLastError());
             if (level == 0) c->primary_events.push_back(launches);
             ++launches;
             n_level = 0;
             if (a.export_below > 1u) {       // how many paths were handed off?
-                HIP_TRY(hipMemcpyAsync(c->h_ovf, a.ovf_out_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpyAsync(c->h_ovf, a.ovf_out_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+                HIP_TRY(hipStreamSynchronize(ls));
                 n_level = c->h_ovf[0];
+            }
+            if (overlap && level == 0) {     // the tail of this batch (side stream) starts when its level-0 launch is through
+                HIP_TRY(hipEventRecord(c->ev_l0[par], st));
+                HIP_TRY(hipStreamWaitEvent(side, c->ev_l0[par], 0));
             }
         }
         ptk::ResolveArgs r{};
-        r.lsamp = c->lsamp.p;
+        r.lsamp = lsamp_b;
         r.film = c->film.p;
         r.out_linear = d_linear;
         r.out_rgba = d_rgba;
@@ -517,9 +563,12 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         r.store_film = batch + 1 < n_batches || c->prog_store;
         r.finalize = batch + 1 == n_batches;
         r.spp_div = c->prog_div ? c->prog_div : prm->spp;
-        ptk::launch_resolve(r, st);
+        ptk::launch_resolve(r, side);
         HIP_TRY(hipGetLastError());
+        if (overlap) HIP_TRY(hipEventRecord(c->ev_resolved[par], side));
     }
+    if (overlap)        // the caller's stream is complete when the last resolve is (the side stream is in order)
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
     HIP_TRY(hipEventRecord(c->ev_end, st));
     HIP_TRY(hipMemcpyAsync(c->h_dstats, c->dstats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     c->stats.samples = (uint64_t)np * prm->spp;
