@@ -63,7 +63,10 @@ constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
 // 4 waves/SIMD: 2048 workgroups 11.6 ms, 8192 10.7, 16384 10.2 (best), 32768 10.6, 65536 11.7).
 constexpr uint32_t kPathsPerWaveLds = 672;
 constexpr uint32_t kPathsPerWave = 1024;
-constexpr uint32_t kMinGrid = 256 * 8;         // at least two rounds of 4 resident workgroups per CU
+constexpr uint32_t kMinGrid = 256 * 8;         // level-0 launches: at least this many workgroups (small renders)
+// continuation launches: one resident round at 6 waves/SIMD.  Their paths are sparse survivors; more, emptier
+// segments cost lane utilisation (measured on C2, ms per step: 1536 -> 9.40, 2048 -> 9.47, 3072 -> 9.69, 6144 -> 10.18)
+constexpr uint32_t kContGrid = 256 * 6;
 // Tail hand-off: in launches of more than kExportMinPaths paths a wave whose segment falls below one chunk
 // exports its leftovers to the overflow queue instead of walking them alone; the next launch takes them up.
 // Measured (C2 / C1 ms per 1024^2 x 64 render): no hand-off 10.33 / 18.5; threshold 2^18 (3-4 levels) 11.2 / 16.9;
@@ -517,7 +520,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             uint32_t g = grid;
             if (level > 0) {
                 const uint64_t want = ((uint64_t)n_level + (uint64_t)paths_per_wave * kWavesPerBlock - 1) / ((uint64_t)paths_per_wave * kWavesPerBlock);
-                g = (uint32_t)std::max<uint64_t>(want, kMinGrid);
+                g = (uint32_t)std::max<uint64_t>(want, kContGrid);
                 g = std::min<uint32_t>(g, (chunks + kWavesPerBlock - 1) / kWavesPerBlock);
             }
             const uint32_t nw_l = g * kWavesPerBlock;
