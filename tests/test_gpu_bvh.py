@@ -234,3 +234,38 @@ def test_bvh_with_unusual_t_min(pt, gpu_ctx, t_min):
     gpu_ctx.upload(pt.builtin_scene(4, 600))
     for t_max in (-0.5, 0.0, 0.5 * t_min, float("nan")):
         _same_hits(gpu_ctx, rays, t_min, t_max)
+
+
+def test_bvh_on_a_triangle_mesh(pt, gpu_ctx):
+    """A bumpy terrain of 2 * 100 * 100 triangles (shared edges and vertices: rays through edges hit two triangles
+    at equal or nearly equal t) under a sphere light, with a glass and a metal sphere: film and counters of the BVH
+    render equal the linear scan's, both arithmetic modes."""
+    rng = np.random.default_rng(1)
+    n = 100
+    xs, zs = np.linspace(-2.0, 2.0, n + 1), np.linspace(-5.0, -1.0, n + 1)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = -0.8 + 0.15 * np.sin(3 * X) * np.cos(2.5 * Z) + 0.02 * rng.standard_normal(X.shape)
+    P = np.stack([X, Y, Z], -1)
+    specs = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = P[i, j], P[i + 1, j], P[i + 1, j + 1], P[i, j + 1]
+            specs.append((1, list(a) + list(c) + list(b), 0, [0.7, 0.7, 0.7]))
+            specs.append((1, list(a) + list(d) + list(c), 0, [0.4, 0.6, 0.4]))
+    specs.append((0, [0.0, 1.6, -3.0, 0.5], 1, [12.0, 12.0, 12.0]))
+    specs.append((0, [-0.7, -0.35, -2.6, 0.3], 2, [0.1, 0.95, 0.95, 0.95, 1.0, 1.5]))
+    specs.append((0, [0.8, -0.3, -3.2, 0.35], 2, [0.05, 1.0, 1.0, 1.0, 0.0, 1.5]))
+    objs = pt.make_objects(specs)
+    depth, nodes, slots = pt.bvh_check(objs)
+    assert slots == len(objs)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_look_at((0.0, 1.0, 1.5), (0.0, -0.6, -3.0), (0.0, 1.0, 0.0), 128, 128, 40.0)
+    for exact_math in (1, 0):
+        out = []
+        for accel in (1, 0):
+            lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=4, accel=accel, exact_math=exact_math))
+            st = gpu_ctx.stats()
+            out.append((lin.cpu().numpy(), rgba.cpu().numpy(), (st.vertices, st.shadow_rays, st.max_depth_reached)))
+        assert out[0][2] == out[1][2]
+        assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][0].mean() > 0.01
