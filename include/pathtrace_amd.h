@@ -73,6 +73,7 @@ typedef struct {
 } PtObject;
 
 enum { PT_INTEGRATOR_MIS = 0, PT_INTEGRATOR_BRDF_ONLY = 1 };
+enum { PT_ACCEL_LINEAR = 0, PT_ACCEL_BVH = 1, PT_ACCEL_AUTO = 2 };
 
 /* Compile-time constants of the reference made runtime parameters
  * (src/world.rs:16-18, src/rendering.rs:6-10).  pt_default_params() fills the
@@ -104,11 +105,13 @@ typedef struct {
      * is bit-identical to the f32 CPU oracle, and the render is ~1.3x slower.  Both modes meet the
      * FP32 tolerance against the f64 reference arithmetic.                      */
     uint32_t exact_math;
-    /* How World::hit_scene (world.rs:270-290) finds the closest hit.  0 (default): the reference's linear
-     * scan over all objects.  1: traversal of a BVH over the objects' bounding boxes, built on the host the
-     * first time a render asks for it (beyond the reference).  The BVH only prunes the scan:
-     * the primitive tests and the winner (smallest t; among equal t the highest object index) are those of
-     * the linear scan, and the film is identical.  Worth it for scenes of hundreds of objects and more.    */
+    /* How World::hit_scene (world.rs:270-290) finds the closest hit.  PT_ACCEL_LINEAR: the reference's linear
+     * scan over all objects.  PT_ACCEL_BVH: traversal of a BVH over the objects' bounding boxes, built on the
+     * host the first time a render asks for it (beyond the reference).  The BVH only prunes the
+     * scan: the primitive tests and the winner (smallest t; among equal t the highest object index) are those of
+     * the linear scan, and the film is identical -- so which one runs is a performance decision only.
+     * PT_ACCEL_AUTO (default): the BVH for scenes of more than 512 objects (where it is faster), the scan
+     * otherwise and for scenes the BVH refuses (an object with a NaN/inf coordinate).                      */
     uint32_t accel;
 } PtRenderParams;
 

@@ -76,6 +76,9 @@ constexpr uint32_t kContGrid = 256 * 6;
 #endif
 constexpr uint32_t kExportMinPaths = 1u << PT_EXPORT_MIN_LOG2;
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
+// PT_ACCEL_AUTO: the BVH from this many objects on (C4-like sphere scenes: the tiled scan costs ~0.11 ms per object
+// and 67 M samples, the BVH ~70 ms flat -> break-even near 600; triangles cost the scan 2.5x more)
+constexpr uint32_t kAutoBvhObjects = 512;
 
 }  // namespace
 
@@ -95,6 +98,7 @@ struct PtContext {
     DevBuf<float4> bvh_nodes, bvh_rec;
     DevBuf<uint32_t> bvh_ids;
     bool has_bvh = false;
+    bool bvh_refused = false;         // the scene has a non-finite object: PT_ACCEL_AUTO stays with the linear scan
     uint32_t bvh_depth = 0;
     // wavefront state
     DevBuf<float4> queue[4];
@@ -171,12 +175,16 @@ void shape_records(const PtObject& o, float4 gather[3], float4 scan[3], int* n_s
 // Build and upload the BVH of the uploaded scene (once per scene).
 int ensure_bvh(PtContext* c) {
     if (c->has_bvh) return PT_OK;
+    if (c->bvh_refused) return fail(PT_ERR_UNSUPPORTED, "accel: the scene has object(s) with a NaN/inf coordinate; use the linear scan");
     if (c->view.n_objs >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "accel: %u objects exceed the 2^28 leaf slots", c->view.n_objs);
     ptbvh::Built b = ptbvh::build(c->h_shape.data(), c->h_shape_tag.data(), c->view.n_objs);
     static_assert(ptbvh::kStackDepth == ptk::kBvhStack, "traversal stack depth");
     static_assert(ptbvh::kMaxLeaf == ptk::kBvhMaxLeaf, "leaf size the traversal unrolls for");
-    if (b.non_finite) return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate; the linear scan's answer for them "
-                                  "depends on the scan order, use accel = 0", b.non_finite);
+    if (b.non_finite) {
+        c->bvh_refused = true;
+        return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate; the linear scan's answer for them "
+                                        "depends on the scan order, use the linear scan", b.non_finite);
+    }
     if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
     int rc;
     if ((rc = c->bvh_nodes.ensure(b.nodes.size() + 4)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
@@ -215,6 +223,7 @@ void pt_default_params(PtRenderParams* p) {
     p->band_count = 1;
     p->max_paths_in_flight = 0;
     p->profile = 0;
+    p->accel = PT_ACCEL_AUTO;
 }
 
 uint32_t pt_tile_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count) {
@@ -375,6 +384,7 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
         if (objs[i].mat_tag != PT_MAT_LAMBERT && objs[i].mat_tag != PT_MAT_EMISSIVE) c->view.diffuse_only = 0u;
     c->view.bvh = ptk::BvhView{};
     c->has_bvh = false;
+    c->bvh_refused = false;
     c->h_shape.assign(shape.begin(), shape.begin() + 3 * (size_t)n);
     c->h_shape_tag.resize(n);
     for (uint32_t i = 0; i < n; ++i) c->h_shape_tag[i] = objs[i].shape_tag;
@@ -389,11 +399,17 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         return fail(PT_ERR_INVALID_ARG, "camera %ux%u: width and height must be >= 2", cam->width, cam->height);
     if (prm->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
     if (prm->integrator > PT_INTEGRATOR_BRDF_ONLY) return fail(PT_ERR_INVALID_ARG, "unknown integrator %u", prm->integrator);
-    if (prm->accel > 1u) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", prm->accel);
+    if (prm->accel > PT_ACCEL_AUTO) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", prm->accel);
     const uint32_t band_count = prm->band_count ? prm->band_count : 1;
     if (prm->band_index >= band_count) return fail(PT_ERR_INVALID_ARG, "band_index %u >= band_count %u", prm->band_index, band_count);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    PtRenderParams resolved = *prm;      // PT_ACCEL_AUTO -> what actually runs
+    if (prm->accel == PT_ACCEL_AUTO) {
+        resolved.accel = PT_ACCEL_LINEAR;
+        if (c->view.n_objs > kAutoBvhObjects && !c->bvh_refused && ensure_bvh(c) == PT_OK) resolved.accel = PT_ACCEL_BVH;
+    }
+    prm = &resolved;
 
     std::vector<uint32_t> rows = tile_row_list(cam->height, prm->band_rows, prm->band_index, band_count);
     const uint64_t np64 = (uint64_t)rows.size() * cam->width;
@@ -621,9 +637,10 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
                        uint32_t accel, int32_t* out_id, float* out_t) {
     if (!c || !rays || !out_id || !out_t) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
-    if (accel > 1u) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", accel);
+    if (accel > PT_ACCEL_AUTO) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", accel);
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
+    if (accel == PT_ACCEL_AUTO) accel = (c->view.n_objs > kAutoBvhObjects && !c->bvh_refused && ensure_bvh(c) == PT_OK) ? PT_ACCEL_BVH : PT_ACCEL_LINEAR;
     if (accel) { int rb = ensure_bvh(c); if (rb) return rb; }
     std::vector<float> r6(6 * (size_t)n);
     for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];

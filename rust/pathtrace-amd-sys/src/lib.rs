@@ -20,6 +20,9 @@ pub const PT_MAT_MIRROR: u32 = 2;
 pub const PT_MAT_OREN_NAYAR: u32 = 3;
 pub const PT_INTEGRATOR_MIS: u32 = 0;
 pub const PT_INTEGRATOR_BRDF_ONLY: u32 = 1;
+pub const PT_ACCEL_LINEAR: u32 = 0;
+pub const PT_ACCEL_BVH: u32 = 1;
+pub const PT_ACCEL_AUTO: u32 = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]

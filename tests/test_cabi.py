@@ -51,6 +51,7 @@ def test_default_params_are_the_reference_constants(pt):
     p = pt.default_params()
     assert (p.spp, p.min_depth, p.max_depth, p.integrator, p.t_min) == (3000, 4, 50, 0, 0.001)   # world.rs:18, rendering.rs:6-7
     assert (p.band_index, p.band_count, p.spp_offset) == (0, 1, 0)
+    assert (p.exact_math, p.accel) == (0, 2)          # fast arithmetic; PT_ACCEL_AUTO (same film either way)
 
 
 def test_builtin_scene_1_is_world_new(pt):

@@ -269,3 +269,21 @@ def test_bvh_on_a_triangle_mesh(pt, gpu_ctx):
         assert out[0][2] == out[1][2]
         assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1], out[1][1])
     assert out[0][0].mean() > 0.01
+
+
+def test_auto_accel_picks_by_scene_size_and_never_changes_the_film(pt, gpu_ctx):
+    """PT_ACCEL_AUTO (the default): linear scan up to 512 objects, BVH above, linear again for a scene the BVH
+    refuses -- the film is the same in every case, only bounce-kernel choice differs."""
+    cam = pt.camera_new(width=48, height=48)
+    for n, refused in ((300, False), (900, False), (900, True)):
+        objs = pt.builtin_scene(4, n)
+        if refused:
+            objs[5].shape[0] = float("nan")
+        gpu_ctx.upload(objs)
+        auto, _ = gpu_ctx.render(cam, pt.default_params(spp=4))
+        lin, _ = gpu_ctx.render(cam, pt.default_params(spp=4, accel=0))
+        assert pt.default_params().accel == 2
+        assert np.array_equal(auto.cpu().numpy(), lin.cpu().numpy(), equal_nan=True), (n, refused)
+        ids_a, t_a = gpu_ctx.debug_hit_scene(_rays(np.random.default_rng(n), 20000), accel=2)
+        ids_l, t_l = gpu_ctx.debug_hit_scene(_rays(np.random.default_rng(n), 20000), accel=0)
+        assert np.array_equal(ids_a, ids_l) and np.array_equal(t_a.view(np.uint32), t_l.view(np.uint32))

@@ -80,7 +80,7 @@ def test_config4_ten_thousand_spheres_small(pt, orc, gpu_ctx):
     test_c4_is_chaotic_paths_agree_only_as_a_prefix): per-pixel agreement is bounded by decorrelated paths,
     so the f64 bar here is >= 93 % of pixels within tolerance and the image mean within 1e-2
     (Monte-Carlo noise between decorrelated paths at 4 spp)."""
-    _check(pt, orc, gpu_ctx, pt.builtin_scene(4, 10000), pt.camera_new(width=48, height=48), pt.default_params(spp=4),
+    _check(pt, orc, gpu_ctx, pt.builtin_scene(4, 10000), pt.camera_new(width=48, height=48), pt.default_params(spp=4, accel=0),
            f64_frac=0.93, f64_mean=1e-2, fast_close=0.88, vert_rel=2e-3)
 
 
@@ -89,7 +89,7 @@ def test_mixed_runs_triangles_and_spheres_tiled(pt, orc, gpu_ctx):
     base = list(pt.builtin_scene(1))
     many = list(pt.builtin_scene(4, 1500))
     objs = (pt._lib.PtObject * (len(base) + len(many)))(*(many[:700] + base[:6] + many[700:] + base[6:]))
-    _check(pt, orc, gpu_ctx, objs, pt.camera_new(width=40, height=40), pt.default_params(spp=4),
+    _check(pt, orc, gpu_ctx, objs, pt.camera_new(width=40, height=40), pt.default_params(spp=4, accel=0),   # the tiled scan
            f64_frac=0.95, f64_mean=1e-2, fast_close=0.93, vert_rel=2e-3)      # contains 1500 of the tiny C4 spheres: partly chaotic
 
 

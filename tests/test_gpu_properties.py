@@ -63,15 +63,15 @@ def test_c4_ten_thousand_spheres_full_width_determinism(pt, gpu_ctx):
     """The tiled-LDS path at the C4 scene size: deterministic and band-invariant (1024 wide, 64 rows, 8 spp)."""
     gpu_ctx.upload(pt.builtin_scene(4, 10000))
     cam = pt.camera_new(width=1024, height=64)
-    a, a8, sa = _render(pt, gpu_ctx, cam, spp=8)
+    a, a8, sa = _render(pt, gpu_ctx, cam, spp=8, accel=0)
     for wg in (0, 0, 7, 64, 2048):           # repeated and differently scheduled renders: a race in the
-        r, r8, sr = _render(pt, gpu_ctx, cam, spp=8, workgroups=wg)   # workgroup-level compaction shows up here
+        r, r8, sr = _render(pt, gpu_ctx, cam, spp=8, accel=0, workgroups=wg)   # workgroup-level compaction shows up here
         assert np.array_equal(a, r) and np.array_equal(a8, r8) and sa.vertices == sr.vertices, wg
-    b, b8, sb = _render(pt, gpu_ctx, cam, spp=8, max_paths_in_flight=3 * 1024 * 64, workgroups=100)
+    b, b8, sb = _render(pt, gpu_ctx, cam, spp=8, accel=0, max_paths_in_flight=3 * 1024 * 64, workgroups=100)
     assert np.array_equal(a, b) and np.array_equal(a8, b8) and sa.vertices == sb.vertices
     frame = np.zeros_like(a)
     for g in range(4):
-        t, _, _ = _render(pt, gpu_ctx, cam, spp=8, band_rows=8, band_index=g, band_count=4)
+        t, _, _ = _render(pt, gpu_ctx, cam, spp=8, accel=0, band_rows=8, band_index=g, band_count=4)
         frame[pt.tile_row_indices(64, 8, g, 4)] = t
     assert np.array_equal(frame, a)
 

@@ -64,6 +64,6 @@ def test_struct_fields_match_the_header():
 
 def test_constants_match_the_header():
     hdr = _strip_comments(HEADER)
-    for m in re.finditer(r"(PT_(?:OK|ERR|SHAPE|MAT|INTEGRATOR)_?\w*)\s*=\s*(\d+)", hdr):
+    for m in re.finditer(r"(PT_(?:OK|ERR|SHAPE|MAT|INTEGRATOR|ACCEL)_?\w*)\s*=\s*(\d+)", hdr):
         assert re.search(r"pub const %s: \w+ = %s;" % (m.group(1), m.group(2)), RUST), m.group(1)
     assert re.search(r"#define PT_ABI_VERSION (\d+)", HEADER).group(1) == re.search(r"PT_ABI_VERSION: u32 = (\d+);", RUST).group(1)
