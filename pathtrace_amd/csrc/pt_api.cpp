@@ -109,6 +109,7 @@ struct PtContext {
     // level-0 launch of batch k + 1 runs on the caller's stream (their own queue and a second sample buffer)
     hipStream_t side_stream = nullptr;
     DevBuf<float4> cqueue[4];
+    DevBuf<float4> caux, csray[2];    // ... and, for accel = 1, its own staged-pass scratch
     DevBuf<float4> lsamp2;
     hipEvent_t ev_l0[2] = {nullptr, nullptr}, ev_resolved[2] = {nullptr, nullptr};
     uint32_t* h_ovf = nullptr;        // pinned read-back of one counter
@@ -278,6 +279,7 @@ int pt_context_destroy(PtContext* c) {
     for (auto& b : c->queue) b.release();
     for (auto& par : c->ovf) for (auto& q : par) for (auto& b : q) b.release();
     for (auto& b : c->cqueue) b.release();
+    c->caux.release(); c->csray[0].release(); c->csray[1].release();
     c->lsamp2.release();
     for (int k = 0; k < 2; ++k) {
         if (c->ev_l0[k]) (void)hipEventDestroy(c->ev_l0[k]);
@@ -456,7 +458,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const size_t q_slots_cont = (size_t)nw * export_max + 64u + (size_t)nw_cont * 64u;
     const size_t q_slots = std::max((size_t)nw * seg_cap, q_slots_cont);
     // Multi-batch renders overlap the tail of batch k (continuation launches, resolve) with the body of batch k + 1
-    const bool overlap = n_batches > 1 && !prm->accel;
+    const bool overlap = n_batches > 1;
 
     int rc;
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
@@ -470,6 +472,9 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     if (overlap)
         for (int k = 0; k < 4; ++k)
             if ((rc = c->cqueue[k].ensure(q_slots_cont))) return rc;
+    if (overlap && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
+                                  (rc = c->csray[1].ensure(q_slots_cont))))
+        return rc;
     if ((rc = c->ovf_count.ensure(4))) return rc;
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
@@ -481,7 +486,6 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
 
     ptk::BounceArgs a{};
     a.seg_cap = seg_cap;
-    a.aux = c->bvh_aux.p; a.sray0 = c->bvh_sray[0].p; a.sray1 = c->bvh_sray[1].p;
     a.stats = c->dstats.p;
     {   // tile row -> image row without a table (ptk::TileMap)
         const uint32_t br = prm->band_rows ? prm->band_rows : cam->height;
@@ -544,8 +548,12 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             a.seg_cap = ((chunks + nw_l - 1) / nw_l) * 64u;
             a.src_mode = level > 0 ? 1u : 0u;
             a.export_below = (hand_off && n_level > kExportMinPaths) ? (small_scene ? export_small : ptk::kBlock) : 1u;
+            const bool own = overlap && level > 0;       // continuation launches of an overlapped batch: their own queue
+            a.aux = own ? c->caux.p : c->bvh_aux.p;
+            a.sray0 = own ? c->csray[0].p : c->bvh_sray[0].p;
+            a.sray1 = own ? c->csray[1].p : c->bvh_sray[1].p;
             for (int k = 0; k < 4; ++k) {
-                a.q.q[k] = (overlap && level > 0) ? c->cqueue[k].p : c->queue[k].p;
+                a.q.q[k] = own ? c->cqueue[k].p : c->queue[k].p;
                 a.ovf_out.q[k] = hand_off ? c->ovf[par][level & 1][k].p : nullptr;
                 a.ovf_in.q[k] = hand_off ? c->ovf[par][(level + 1) & 1][k].p : nullptr;
             }
