@@ -110,8 +110,9 @@ typedef struct {
      * host the first time a render asks for it (beyond the reference).  The BVH only prunes the
      * scan: the primitive tests and the winner (smallest t; among equal t the highest object index) are those of
      * the linear scan, and the film is identical -- so which one runs is a performance decision only.
-     * PT_ACCEL_AUTO (default): the BVH for scenes of more than 512 objects (where it is faster), the scan
-     * otherwise and for scenes the BVH refuses (an object with a NaN/inf coordinate).                      */
+     * PT_ACCEL_AUTO (default): the BVH where it is faster -- scenes of more than 128 objects whose scan costs
+     * more than ~512 sphere tests (a triangle counts 2.5) --, the scan otherwise and for scenes the BVH refuses
+     * (an object with a NaN/inf coordinate).                                                                */
     uint32_t accel;
 } PtRenderParams;
 

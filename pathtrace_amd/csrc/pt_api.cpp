@@ -76,9 +76,10 @@ constexpr uint32_t kContGrid = 256 * 6;
 #endif
 constexpr uint32_t kExportMinPaths = 1u << PT_EXPORT_MIN_LOG2;
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
-// PT_ACCEL_AUTO: the BVH from this many objects on (C4-like sphere scenes: the tiled scan costs ~0.11 ms per object
-// and 67 M samples, the BVH ~70 ms flat -> break-even near 600; triangles cost the scan 2.5x more)
-constexpr uint32_t kAutoBvhObjects = 512;
+// PT_ACCEL_AUTO: the BVH when the scene is larger than one LDS blob and spheres + 2.5 x triangles > 512 (C4-like
+// scenes: the tiled scan costs ~0.11 ms per sphere and 67 M samples -- a Moeller-Trumbore test 2.5x that --, the BVH
+// ~70 ms flat -> break-even near 600 sphere tests)
+constexpr uint32_t kAutoBvhWeight = 512;
 
 }  // namespace
 
@@ -99,6 +100,7 @@ struct PtContext {
     DevBuf<uint32_t> bvh_ids;
     bool has_bvh = false;
     bool bvh_refused = false;         // the scene has a non-finite object: PT_ACCEL_AUTO stays with the linear scan
+    bool auto_bvh = false;            // PT_ACCEL_AUTO would take the BVH for this scene (size rule above)
     uint32_t bvh_depth = 0;
     // wavefront state
     DevBuf<float4> queue[4];
@@ -387,6 +389,11 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     c->view.bvh = ptk::BvhView{};
     c->has_bvh = false;
     c->bvh_refused = false;
+    {
+        uint64_t tris = 0;
+        for (uint32_t i = 0; i < n; ++i) tris += objs[i].shape_tag == PT_SHAPE_TRIANGLE;
+        c->auto_bvh = n > ptk::kSmallObjs && 2 * (uint64_t)(n - tris) + 5 * tris > 2 * (uint64_t)kAutoBvhWeight;
+    }
     c->h_shape.assign(shape.begin(), shape.begin() + 3 * (size_t)n);
     c->h_shape_tag.resize(n);
     for (uint32_t i = 0; i < n; ++i) c->h_shape_tag[i] = objs[i].shape_tag;
@@ -409,7 +416,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     PtRenderParams resolved = *prm;      // PT_ACCEL_AUTO -> what actually runs
     if (prm->accel == PT_ACCEL_AUTO) {
         resolved.accel = PT_ACCEL_LINEAR;
-        if (c->view.n_objs > kAutoBvhObjects && !c->bvh_refused && ensure_bvh(c) == PT_OK) resolved.accel = PT_ACCEL_BVH;
+        if (c->auto_bvh && !c->bvh_refused && ensure_bvh(c) == PT_OK) resolved.accel = PT_ACCEL_BVH;
     }
     prm = &resolved;
 
@@ -648,7 +655,7 @@ int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_mi
     if (accel > PT_ACCEL_AUTO) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", accel);
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (accel == PT_ACCEL_AUTO) accel = (c->view.n_objs > kAutoBvhObjects && !c->bvh_refused && ensure_bvh(c) == PT_OK) ? PT_ACCEL_BVH : PT_ACCEL_LINEAR;
+    if (accel == PT_ACCEL_AUTO) accel = (c->auto_bvh && !c->bvh_refused && ensure_bvh(c) == PT_OK) ? PT_ACCEL_BVH : PT_ACCEL_LINEAR;
     if (accel) { int rb = ensure_bvh(c); if (rb) return rb; }
     std::vector<float> r6(6 * (size_t)n);
     for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];
