@@ -56,7 +56,7 @@ def test_random_scene_matches_f32_oracle(pt, orc, gpu_ctx, seed):
         cam = pt.camera_look_at(tuple(rng.uniform([-0.8, -0.8, 0.5], [0.8, 0.8, 2.5])), (0.0, 0.0, -2.0), (0.0, 1.0, 0.0),
                                 w, h, float(rng.uniform(25, 60)))
     prm = pt.default_params(spp=int(rng.integers(1, 6)), integrator=int(rng.integers(0, 2)),
-                            min_depth=int(rng.integers(0, 6)), max_depth=int(rng.integers(6, 30)), exact_math=1)
+                            min_depth=int(rng.integers(0, 6)), max_depth=int(rng.integers(6, 30)), exact_math=1, accel=0)
     gpu_ctx.upload(objs)
     lin, rgba = gpu_ctx.render(cam, prm)
     st = gpu_ctx.stats()
