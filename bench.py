@@ -96,6 +96,20 @@ def cpu_baseline(pt, objs):
     }
 
 
+def pmc_valu(world, workload="c2"):
+    """VALU issue figures of the same kernel from the same profile file (static, like `traffic`): the kernel is
+    VALU-bound, which the hbm|mfma `bound` field cannot say."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    if world != 1 or workload != "c2" or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            v = json.load(f).get("valu")
+        return {k: v[k] for k in ("insts_per_launch", "cycles_per_inst_per_simd", "ubench_cycles_per_inst", "frac_of_ubench_rate")} if v else None
+    except Exception:
+        return None
+
+
 def pmc_traffic(world, workload="c2"):
     """HBM bytes per k_paths launch from the committed rocprofv3 PMC passes (profiles/r01/traffic.json:
     FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command, tools/profile_gpu.sh).
@@ -270,6 +284,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(world, args.workload),
+                "valu": pmc_valu(world, args.workload),
                 "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["p_launches"], 1)),
                 "avg_launch_ms": round(acc["p_ms"] / max(acc["p_launches"], 1), 4),
                 "launches": acc["p_launches"],
