@@ -473,9 +473,10 @@ k_paths(BounceArgs a) {
 
     for (uint32_t it = 0; it < n_iter; ++it) {
         bool active;
-        PathState p = parked_state();
+        PathState p;
 
         if (first) {
+            p = parked_state();
             const uint32_t chunk = it * nw + wave;
             const uint32_t pid = chunk * 64u + lane;
             active = chunk < n_chunks && pid < a.n_first;
@@ -491,11 +492,12 @@ k_paths(BounceArgs a) {
                 }
             }
         } else {
+            // every lane loads its slot (the last chunk of a pass reads stale slots of the segment: in bounds, and a
+            // lane without a path only needs a ray that hits nothing -- its other fields are never looked at)
             active = it * chunk_slots + lane_off < n_in;
-            if (active) {
-                const uint32_t s0 = seg_base + it * chunk_slots + lane_off;
-                p = unpack_state(a.q.q[0][s0], a.q.q[1][s0], a.q.q[2][s0], a.q.q[3][s0]);
-            }
+            const uint32_t s0 = seg_base + it * chunk_slots + lane_off;
+            p = unpack_state(a.q.q[0][s0], a.q.q[1][s0], a.q.q[2][s0], a.q.q[3][s0]);
+            if (!active) { p.o = parked_origin(); p.d = parked_dir(); }
         }
         const uint32_t py = image_row(a.tile, p.yl);     // key of the path's RNG stream = (x, y), main.rs:51
         const uint32_t sample = a.s_base + p.s_local;
