@@ -459,7 +459,9 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     const bool hand_off = true;
     const bool small_scene = c->view.n_objs <= ptk::kSmallObjs || prm->accel;     // the tiled scan exports per workgroup (< 256 paths)
     const uint32_t nw_cont = std::max(nw, kMinGrid * kWavesPerBlock);    // waves of any continuation launch
-    const uint32_t export_max = std::max(export_small, ptk::kBlock);      // a wave exports < export_small paths, a tiled workgroup < 256
+    // leftovers per wave of a launch: < export_small from a wave-private segment, < 256 per workgroup (= 64 per wave)
+    // from a workgroup-shared one
+    const uint32_t export_max = std::max(export_small, 64u);
     const size_t ovf_slots = (size_t)nw_cont * export_max;
     // level 0 needs nw*seg_cap slots; a continuation launch of n < nw*export_max paths needs <= n + 64 + nw_cont*64
     const size_t q_slots_cont = (size_t)nw * export_max + 64u + (size_t)nw_cont * 64u;
