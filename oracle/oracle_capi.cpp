@@ -185,7 +185,8 @@ extern "C" void orc_bsdf_eval(const PtObject* po, int precision, const double* i
     if (precision == 64) bsdf_eval_batch<double>(po, in, n, out); else bsdf_eval_batch<float>(po, in, n, out);
 }
 
-// Material::bsdf_pdf_sample: in n*(dir_in3, normal3, eta), draws n*4 u32; out n*8 (wo3, f3, pdf, cos)
+// Material::bsdf_pdf_sample: in n*(dir_in3, normal3, eta), draws n*4 u32 = (r1, r2, lobe u, unused) raw words;
+// out n*8 (wo3, f3, pdf, cos)
 template <class R>
 static void bsdf_sample_batch(const PtObject* po, const double* in, const uint32_t* draws, uint32_t n, double* out) {
     Scene<R> sc = build_scene<R>(po, 1);
@@ -194,7 +195,7 @@ static void bsdf_sample_batch(const PtObject* po, const double* in, const uint32
         Ray<R> ray; ray.direction = V3<R>((R)q[0], (R)q[1], (R)q[2]); ray.eta_ratio = (R)q[6];
         V3<R> nn((R)q[3], (R)q[4], (R)q[5]);
         V3<R> wo, f; R pdf, c;
-        bsdf_pdf_sample<R>(sc.objs[0], ray, nn, draws + 4 * i, wo, f, pdf, c);
+        bsdf_pdf_sample<R>(sc.objs[0], ray, nn, draws[4 * i], draws[4 * i + 1], draws[4 * i + 2], wo, f, pdf, c);
         double v[8] = {wo.x, wo.y, wo.z, f.x, f.y, f.z, (double)pdf, (double)c};
         std::memcpy(out + 8 * i, v, sizeof v);
     }

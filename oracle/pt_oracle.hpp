@@ -65,12 +65,16 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Draw blocks per vertex (regrouped so that one block serves
-// the BRDF-only integrator):
-//   block 0 (light): [0] light index (raw u32) [1] light r1 [2] light r2 [3] spare
-//   block 1 (bsdf):  [0] bsdf r1 [1] bsdf r2 [2] Mirror lobe u [3] Russian roulette u
+// Draw blocks per vertex (the dimensions of SURVEY Appendix A, regrouped by HOW OFTEN a vertex needs them):
+//   block 0 (surface): [0] light r1 [1] light r2 [2] bsdf r1 [3] bsdf r2       -- every non-emitter vertex
+//   block 1 (choice):  [0] light index (raw u32) [1] Mirror lobe u [2] Russian roulette u [3] spare
+// Block 1 decides nothing at a vertex of a Lambertian / OrenNayar surface with one light in the scene and
+// depth < MIN_DEPTH (index = umulhi(u, 1) = 0; rr = 1 > every uniform): the device does not generate it there
+// (one Philox call per vertex instead of two for the first MIN_DEPTH bounces), the oracle always does.
 // Camera jitter: depth = 0xFFFFFFFF, block 0: [0] ox [1] oy   (world.rs:299: ox first)
-enum { BLK_LIGHT = 0, BLK_BSDF = 1, DEPTH_CAMERA = 0xFFFFFFFFu };
+enum { BLK_SURFACE = 0, BLK_CHOICE = 1, DEPTH_CAMERA = 0xFFFFFFFFu };
+enum { DIM_LIGHT_R1 = 0, DIM_LIGHT_R2 = 1, DIM_BSDF_R1 = 2, DIM_BSDF_R2 = 3 };       // words of BLK_SURFACE
+enum { DIM_LIGHT_INDEX = 0, DIM_LOBE = 1, DIM_RR = 2 };                             // words of BLK_CHOICE
 
 // 23-bit uniform on the OPEN interval (0,1): (2k+1)/2^24, exactly representable
 // in f32, so the float and double oracles and the device see the same value.
@@ -716,14 +720,14 @@ inline void bsdf_pdf(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& o, const 
 
 // Object::bsdf_pdf_sample (object.rs:46-54) -> Material::bsdf_pdf_sample
 // (default impl material.rs:29-40; Mirror override mirror.rs:200-305).
-// d4 = the vertex's BLK_BSDF draw block.
+// w_r1, w_r2 = the vertex's BSDF words of BLK_SURFACE, w_lobe = its lobe word of BLK_CHOICE.
 template <class R>
-inline void bsdf_pdf_sample(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& n, const uint32_t d4[4], V3<R>& wo,
-                            V3<R>& f, R& pdf, R& cos_out) {
-    R r1 = (R)u01(d4[0]), r2 = (R)u01(d4[1]);
+inline void bsdf_pdf_sample(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& n, uint32_t w_r1, uint32_t w_r2,
+                            uint32_t w_lobe, V3<R>& wo, V3<R>& f, R& pdf, R& cos_out) {
+    R r1 = (R)u01(w_r1), r2 = (R)u01(w_r2);
     switch (ob.mat_tag) {
         case PT_MAT_MIRROR:
-            mirror_sample(ob, ray, n, r1, r2, (R)u01(d4[2]), wo, f, pdf, cos_out);
+            mirror_sample(ob, ray, n, r1, r2, (R)u01(w_lobe), wo, f, pdf, cos_out);
             return;
         case PT_MAT_EMISSIVE:                                 // sample_direction = normal, material.rs:150-158
             wo = n;
@@ -754,17 +758,19 @@ template <class R> inline int hit_scene(const Scene<R>& w, const Ray<R>& ray, R 
 
 template <class R> struct LightSample { V3<R> point, emission; R pdf; };   // world.rs:48-52
 
-// World::sample_light_point, world.rs:251-267.  d4 = the vertex's BLK_LIGHT block.
+// World::sample_light_point, world.rs:251-267.  w_index = the vertex's light-index word (BLK_CHOICE),
+// w_r1, w_r2 = its light words of BLK_SURFACE.
 // random_range(0..n): rand's widening-multiply reduction, without its rare
 // bias-rejection redraw (a second draw would break (depth,dim) addressing).
 template <class R>
-inline bool sample_light_point(const Scene<R>& w, const Hit<R>& hit, const uint32_t d4[4], LightSample<R>& ls) {
+inline bool sample_light_point(const Scene<R>& w, const Hit<R>& hit, uint32_t w_index, uint32_t w_r1, uint32_t w_r2,
+                               LightSample<R>& ls) {
     if (w.lights.empty()) return false;
     uint32_t n = (uint32_t)w.lights.size();
-    uint32_t li = (uint32_t)(((uint64_t)d4[0] * n) >> 32);
+    uint32_t li = (uint32_t)(((uint64_t)w_index * n) >> 32);
     const Obj<R>& lo = w.objs[w.lights[li]];
     V3<R> normal, dir; R pdf_shape, dist;
-    shape_sample<R>(lo, hit, nullptr, (R)u01(d4[1]), (R)u01(d4[2]), ls.point, normal, pdf_shape, dir, dist);
+    shape_sample<R>(lo, hit, nullptr, (R)u01(w_r1), (R)u01(w_r2), ls.point, normal, pdf_shape, dir, dist);
     ls.emission = emit(lo);
     ls.pdf = pdf_shape / (R)n;
     return true;
@@ -803,11 +809,11 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
     V3<R> emitted = emit(obj);                                                     // :42
     if (emitted.length() > 0) return depth == 0 ? emitted : V3<R>::zero();         // :43-49
     V3<R> total = V3<R>::zero(), direct = V3<R>::zero();
-    uint32_t dl[4], db[4];
-    dr.block(depth, BLK_LIGHT, dl);
-    dr.block(depth, BLK_BSDF, db);
+    uint32_t ds[4], dc[4];
+    dr.block(depth, BLK_SURFACE, ds);
+    dr.block(depth, BLK_CHOICE, dc);
     LightSample<R> ls;
-    if (sample_light_point(w, hit, dl, ls)) {                                      // :56
+    if (sample_light_point(w, hit, dc[DIM_LIGHT_INDEX], ds[DIM_LIGHT_R1], ds[DIM_LIGHT_R2], ls)) {   // :56
         V3<R> to_light = ls.point - hit.point;                                     // :58
         R distance = to_light.length();
         V3<R> light_dir = to_light.normalize();
@@ -826,12 +832,12 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
     total += direct / R(1);                                                        // :81 (NUM_LIGHT_SAMPLES=1)
     ray.eta_ratio = eta_from_object(obj, hit);                                     // :83
     V3<R> wo, bsdf; R pdf, cos_theta;
-    bsdf_pdf_sample(obj, ray, hit.normal, db, wo, bsdf, pdf, cos_theta);           // :84-85
+    bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);   // :84-85
     Ray<R> scattered(hit.point, wo);                                               // :86
     scattered.eta_ratio = eta_from_object(obj, hit);                               // :87
     V3<R> next_tp = throughput * bsdf * cos_theta / pdf;                           // :89
     R rr = rr_prob(p, depth, next_tp);                                             // :91-98
-    if ((R)u01(db[3]) > rr) return V3<R>::zero();                                  // :100-102 (drops `total`, Q1)
+    if ((R)u01(dc[DIM_RR]) > rr) return V3<R>::zero();                             // :100-102 (drops `total`, Q1)
     Hit<R> h2;
     int o2 = hit_scene(w, scattered, tmin, kInf<R>(), h2);                         // :104-105
     cn.scans++;
@@ -871,16 +877,17 @@ V3<R> ray_color_brdf_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32
     const Obj<R>& obj = w.objs[oi];
     V3<R> emitted = emit(obj);
     if (emitted.length() > 0) return emitted;                                      // :225-227
-    uint32_t db[4];
-    dr.block(depth, BLK_BSDF, db);
+    uint32_t ds[4], dc[4];
+    dr.block(depth, BLK_SURFACE, ds);
+    dr.block(depth, BLK_CHOICE, dc);
     ray.eta_ratio = eta_from_object(obj, hit);                                     // :230
     V3<R> wo, bsdf; R pdf, cos_theta;
-    bsdf_pdf_sample(obj, ray, hit.normal, db, wo, bsdf, pdf, cos_theta);           // :231-232
+    bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);   // :231-232
     Ray<R> scattered(hit.point, wo);
     scattered.eta_ratio = eta_from_object(obj, hit);
     V3<R> next_tp = throughput * bsdf * cos_theta / pdf;                           // :236
     R rr = rr_prob(p, depth, next_tp);
-    if ((R)u01(db[3]) > rr) return V3<R>::zero();                                  // :246-248
+    if ((R)u01(dc[DIM_RR]) > rr) return V3<R>::zero();                             // :246-248
     V3<R> li = ray_color_brdf_rec(w, p, scattered, depth + 1, dr, next_tp / rr, cn);
     return bsdf * li * cos_theta / (pdf * rr);                                     // :260
 }
@@ -937,12 +944,13 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
             if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
             break;
         }
-        uint32_t dl[4], db[4];
+        uint32_t ds[4], dc[4];
+        dr.block(depth, BLK_SURFACE, ds);
+        dr.block(depth, BLK_CHOICE, dc);
         V3<R> direct = V3<R>::zero();
         if (mis) {
-            dr.block(depth, BLK_LIGHT, dl);
             LightSample<R> ls;
-            if (sample_light_point(w, hit, dl, ls)) {
+            if (sample_light_point(w, hit, dc[DIM_LIGHT_INDEX], ds[DIM_LIGHT_R1], ds[DIM_LIGHT_R2], ls)) {
                 V3<R> to_light = ls.point - hit.point;
                 R distance = to_light.length();
                 V3<R> light_dir = to_light.normalize();
@@ -961,15 +969,14 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
                 if (T) { T[12] = ls.pdf; T[13] = visible ? 1.0 : 0.0; T[16] = distance; T[17] = direct.x; }
             }
         }
-        dr.block(depth, BLK_BSDF, db);
         R eta_here = eta_from_object(obj, hit);
         ray.eta_ratio = eta_here;
         V3<R> wo, bsdf; R pdf, cos_theta;
-        bsdf_pdf_sample(obj, ray, hit.normal, db, wo, bsdf, pdf, cos_theta);
+        bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);
         V3<R> next_tp = beta * bsdf * cos_theta / pdf;
         R rr = rr_prob(p, depth, next_tp);
-        if (T) { T[18] = pdf; T[19] = rr; T[20] = (double)u01(db[3]); }
-        if ((R)u01(db[3]) > rr) break;                   // drops `direct` too (Q1)
+        if (T) { T[18] = pdf; T[19] = rr; T[20] = (double)u01(dc[DIM_RR]); }
+        if ((R)u01(dc[DIM_RR]) > rr) break;              // drops `direct` too (Q1)
         L += beta * direct;
         if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
         beta = next_tp / rr;

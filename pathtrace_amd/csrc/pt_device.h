@@ -110,7 +110,15 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-enum { BLK_LIGHT = 0, BLK_BSDF = 1 };
+// Draw blocks of a vertex, ctr = (sample, depth, block, 0):
+//   BLK_SURFACE: [0] light r1 [1] light r2 [2] bsdf r1 [3] bsdf r2     (shape.rs:111-112,211-212; material.rs:100-101,
+//                                                                      mirror.rs:42-43)
+//   BLK_CHOICE:  [0] light index (world.rs:255) [1] Mirror lobe u (mirror.rs:232) [2] Russian roulette u
+//                (rendering.rs:100)
+// BLK_CHOICE is generated only where it can decide something: more than one light, a Mirror surface, or
+// depth >= MIN_DEPTH (below it rr = 1 and u < 1 always survives) -- one Philox call per vertex instead of two
+// on the first MIN_DEPTH bounces of a diffuse scene.
+enum { BLK_SURFACE = 0, BLK_CHOICE = 1 };
 constexpr uint32_t kDepthCamera = 0xFFFFFFFFu;
 // 23-bit uniform on the open interval (0,1): (2k+1)/2^24, exact in f32.
 PT_DEV float u01(uint32_t r) { return (float)(((r >> 9) << 1) | 1u) * (1.0f / 16777216.0f); }
@@ -448,12 +456,13 @@ PT_DEV void bsdf_pdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, floa
         oren_nayar_eval(m, dir_in, o, n, f, pdf);
     }
 }
-// Object::bsdf_pdf_sample (object.rs:46-54); d4 = the vertex's BLK_BSDF block
-PT_DEV void bsdf_pdf_sample(const Mat& m, f3 dir_in, float eta, f3 n, const uint32_t d4[4], f3& wo, f3& f,
-                            float& pdf, float& cos_out) {
-    float r1 = u01(d4[0]), r2 = u01(d4[1]);
+// Object::bsdf_pdf_sample (object.rs:46-54); w_r1, w_r2 = the vertex's BSDF words of BLK_SURFACE, w_lobe = its
+// lobe word of BLK_CHOICE (read by Mirror only)
+PT_DEV void bsdf_pdf_sample(const Mat& m, f3 dir_in, float eta, f3 n, uint32_t w_r1, uint32_t w_r2, uint32_t w_lobe,
+                            f3& wo, f3& f, float& pdf, float& cos_out) {
+    float r1 = u01(w_r1), r2 = u01(w_r2);
     if (m.tag == MAT_MIRROR) {
-        mirror_sample(m, dir_in, eta, n, r1, r2, u01(d4[2]), wo, f, pdf, cos_out);
+        mirror_sample(m, dir_in, eta, n, r1, r2, u01(w_lobe), wo, f, pdf, cos_out);
         return;
     }
     wo = (m.tag == MAT_EMISSIVE) ? n : cosine_sample(n, r1, r2);     // material.rs:150-158 / :93-122

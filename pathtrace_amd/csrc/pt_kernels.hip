@@ -259,6 +259,9 @@ struct Vertex {
     bool need_shadow;        // a light point was sampled: visibility of light_dir up to distance is needed
     f3 light_dir, ls_emission;
     float distance, ls_pdf;
+    uint32_t w_bsdf1, w_bsdf2;   // the vertex's BSDF words of BLK_SURFACE (drawn together with the light words)
+    uint32_t w_lobe, w_rr;       // its BLK_CHOICE words, when vertex_begin had to draw that block (several lights)
+    int obj, light_obj;          // object hit (>= 0) and light picked: vertex_end can re-read their records (REMAT)
 };
 
 PT_DEV PathState unpack_state(float4 q0, float4 q1, float4 q2, float4 q3) {
@@ -301,6 +304,21 @@ PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_
     d = normalize(dir);                                                   // Ray::new, camera.rs:13
 }
 
+// World::sample_light_point (world.rs:251-267) from `from`: w_index = the light-index word, w_r1 / w_r2 = the surface words.
+// n_lights > 0.
+template <bool DIFFUSE>
+PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, uint32_t w_r1, uint32_t w_r2, f3& point,
+                               int& lobj, f3& emission, float& pdf) {
+    const uint32_t li = __umulhi(w_index, sc.n_lights);                           // random_range(0..n), world.rs:255
+    lobj = (int)sc.lights[li];
+    const Mat lm = load_mat(sc.mat, lobj);
+    if (DIFFUSE) __builtin_assume(lm.tag <= MAT_EMISSIVE);
+    float pdf_shape;
+    shape_sample(sc.shape, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape);
+    emission = lm.color;                                                          // world.rs:259
+    pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);  // world.rs:260 (x/1 == x)
+}
+
 // (id, t) = closest hit of the path ray, id < 0: miss.  Credits an emitter hit into p.L and samples the light point.
 // DIFFUSE: the scene has Lambertian and emissive materials only (decided at pt_scene_upload); the GGX and
 // OrenNayar code is then compiled out of the kernel (same results; smaller code, no spills at 6 waves/SIMD: C2 +2 %).
@@ -308,6 +326,7 @@ template <bool MIS, bool DIFFUSE>
 PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, float t, uint32_t sample, uint32_t py,
                          Vertex& v) {
     v.alive = active && id >= 0;
+    v.obj = id >= 0 ? id : 0; v.light_obj = 0;
     v.hit.point = p.o; v.hit.normal = p.d; v.hit.t = 0.0f; v.hit.front_face = false;
     v.m.tag = MAT_LAMBERT; v.m.shape_tag = 0; v.m.emits = 0; v.m.color = mk(0.f, 0.f, 0.f);
     v.m.roughness = 0.f; v.m.metallic = 0.f; v.m.ior = 1.f; v.m.on_a = 1.f; v.m.on_b = 0.f;
@@ -330,34 +349,47 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
         }
     }
 
-    // ---- NEE: light pick + surface sample (world.rs:251-267)
+    // ---- draws of the vertex; NEE: light pick + surface sample (world.rs:251-267)
     v.need_shadow = false;
     v.light_dir = mk(0.f, 0.f, 0.f); v.ls_emission = mk(0.f, 0.f, 0.f);
     v.distance = 0.0f; v.ls_pdf = 1.0f;
-    if (MIS && v.alive && sc.n_lights > 0u) {
-        uint32_t dl[4];
-        philox4x32_10(sample, p.depth, BLK_LIGHT, 0u, p.px, py, dl);
-        uint32_t li = __umulhi(dl[0], sc.n_lights);                           // random_range(0..n), world.rs:255
-        int lobj = (int)sc.lights[li];
-        Mat lm = load_mat(sc.mat, lobj);
-        if (DIFFUSE) __builtin_assume(lm.tag <= MAT_EMISSIVE);
-        f3 lp; float pdf_shape;
-        shape_sample(sc.shape, lobj, lm.shape_tag, v.hit.point, false, v.hit.point, u01(dl[1]), u01(dl[2]), lp,
-                     pdf_shape);
-        v.ls_emission = lm.color;                                             // world.rs:259
-        v.ls_pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);   // world.rs:260 (x/1 == x)
-        f3 to_light = lp - v.hit.point;                                       // rendering.rs:58-60
-        v.distance = length(to_light);
-        v.light_dir = normalize(to_light);
-        v.need_shadow = true;
+    v.w_bsdf1 = v.w_bsdf2 = v.w_lobe = v.w_rr = 0u;
+    if (v.alive) {
+        uint32_t ds[4];
+        philox4x32_10(sample, p.depth, BLK_SURFACE, 0u, p.px, py, ds);
+        v.w_bsdf1 = ds[2]; v.w_bsdf2 = ds[3];
+        if (MIS && sc.n_lights > 0u) {
+            uint32_t w_index = 0u;                                                // umulhi(u, 1) = 0: one light needs no draw
+            if (sc.n_lights > 1u) {
+                uint32_t dc[4];
+                philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, p.px, py, dc);
+                w_index = dc[0]; v.w_lobe = dc[1]; v.w_rr = dc[2];
+            }
+            f3 lp;
+            sample_light_point<DIFFUSE>(sc, v.hit.point, w_index, ds[0], ds[1], lp, v.light_obj, v.ls_emission, v.ls_pdf);
+            f3 to_light = lp - v.hit.point;                                       // rendering.rs:58-60
+            v.distance = length(to_light);
+            v.light_dir = normalize(to_light);
+            v.need_shadow = true;
+        }
     }
 }
 
 // visible: the shadow scan found nothing between the vertex and the light point.  Returns "the path goes on";
 // p is then the state at the next vertex.
-template <bool MIS, bool DIFFUSE>
-PT_DEV bool vertex_end(PathState& p, const Vertex& v, bool visible, uint32_t sample, uint32_t py, uint32_t min_depth,
-                       uint32_t max_depth) {
+// REMAT (scene in LDS): the material of the hit object and the light's emission are read again here instead of
+// being carried across the visibility scan -- two broadcast LDS reads instead of ~6 live registers, which is what
+// keeps the kernel at 80 VGPRs without spills.
+template <bool MIS, bool DIFFUSE, bool REMAT>
+PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool visible, uint32_t sample, uint32_t py,
+                       uint32_t min_depth, uint32_t max_depth) {
+    const uint32_t n_lights = sc.n_lights;
+    Vertex v = vin;
+    if (REMAT) {
+        asm volatile("" ::: "memory");          // a real re-read, not the values of vertex_begin kept alive
+        v.m = load_mat(sc.mat, vin.obj);
+        v.ls_emission = load_mat(sc.mat, vin.light_obj).color;
+    }
     if (DIFFUSE) __builtin_assume(v.m.tag <= MAT_EMISSIVE);
     f3 direct = mk(0.f, 0.f, 0.f);
     if (MIS && visible) {
@@ -371,15 +403,21 @@ PT_DEV bool vertex_end(PathState& p, const Vertex& v, bool visible, uint32_t sam
     // ---- BSDF sample, throughput, Russian roulette (rendering.rs:83-102)
     bool alive = v.alive;
     if (alive) {
-        uint32_t db[4];
-        philox4x32_10(sample, p.depth, BLK_BSDF, 0u, p.px, py, db);
+        // BLK_CHOICE: already drawn by vertex_begin when the scene has several lights; otherwise only a Mirror
+        // surface (lobe) or a vertex at depth >= MIN_DEPTH (roulette: below it rr = 1 > every uniform) reads it
+        uint32_t w_lobe = v.w_lobe, w_rr = v.w_rr;
+        if (!(MIS && n_lights > 1u) && (v.m.tag == MAT_MIRROR || p.depth >= min_depth)) {
+            uint32_t dc[4];
+            philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, p.px, py, dc);
+            w_lobe = dc[1]; w_rr = dc[2];
+        }
         float eta_mat = v.m.tag == MAT_MIRROR ? v.m.ior : 1.0f;               // get_eta, material.rs:50 / mirror.rs:317
         float eta_here = v.hit.front_face ? pt_rcp(eta_mat) : eta_mat;         // rendering.rs:20-25
         f3 wo, bsdf; float pdf, cos_theta;
-        bsdf_pdf_sample(v.m, p.d, eta_here, v.hit.normal, db, wo, bsdf, pdf, cos_theta);   // :84-85
+        bsdf_pdf_sample(v.m, p.d, eta_here, v.hit.normal, v.w_bsdf1, v.w_bsdf2, w_lobe, wo, bsdf, pdf, cos_theta);   // :84-85
         f3 next_tp = p.beta * bsdf * cos_theta / pdf;                         // :89
         float rr = rr_prob(p.depth, min_depth, max_depth, next_tp);           // :91-98
-        if (u01(db[3]) > rr) {                                                // :100-102 (drops direct, Q1)
+        if (u01(w_rr) > rr) {                                                 // :100-102 (drops direct, Q1)
             alive = false;
         } else {
             p.L = p.L + p.beta * direct;
@@ -536,7 +574,7 @@ k_paths(BounceArgs a) {
                 wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
         }
-        const bool alive = vertex_end<MIS, DIFFUSE>(p, v, visible, sample, py, a.min_depth, a.max_depth);
+        const bool alive = vertex_end<MIS, DIFFUSE, SMALL>(sc, p, v, visible, sample, py, a.min_depth, a.max_depth);
 
         // ---- retire, or compact in place into the wave's own segment
         if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
@@ -830,7 +868,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             Vertex v;
             vertex_begin<MIS, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, sample, py, v);
             const bool visible = MIS && v.need_shadow && h.z == 0.0f;
-            const bool alive = vertex_end<MIS, DIFFUSE>(p, v, visible, sample, py, a.min_depth, a.max_depth);
+            const bool alive = vertex_end<MIS, DIFFUSE, false>(sc, p, v, visible, sample, py, a.min_depth, a.max_depth);
             if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
             const unsigned long long mask = __ballot(alive);
             if (alive) store_state(q, out_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
