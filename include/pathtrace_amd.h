@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 typedef enum {
     PT_OK = 0,
@@ -114,7 +114,18 @@ typedef struct {
      * more than ~512 sphere tests (a triangle counts 2.5) --, the scan otherwise and for scenes the BVH refuses
      * (an object with a NaN/inf coordinate).                                                                */
     uint32_t accel;
+    /* pt_render() only: render on the first n_devices HIP devices (pt_render_multi: row bands, one RCCL
+     * gather of the film to device 0).  0 or 1: device 0 alone.  The film does not depend on it.               */
+    uint32_t n_devices;
 } PtRenderParams;
+
+/* Scheduling knobs of a context (pt_context_set_tuning); results never depend on them.  0 = library default.   */
+typedef struct {
+    uint32_t export_below;   /* a wave hands its queue segment to the continuation launch below this many paths (64) */
+    uint32_t bvh_refill;     /* accel = 1: idle lanes take new rays when fewer lanes than this are tracing (36)      */
+    uint32_t bvh_leaf;       /* accel = 1: leaf primitives are tested when this many lanes wait at a leaf (24)       */
+    uint32_t reserved;
+} PtTuning;
 
 /* Counters of the last render on a context. */
 typedef struct {
@@ -169,24 +180,30 @@ typedef struct PtContext PtContext;
 int pt_context_create(int device, PtContext** out);
 int pt_context_destroy(PtContext* ctx);
 /* Run the library's kernels on a caller-owned hipStream_t (e.g. torch's current
- * stream) instead of the context's own stream.  NULL restores the default.    */
+ * stream) instead of the context's own (non-blocking) stream.  NULL restores the context's own
+ * stream; PT_STREAM_LEGACY_DEFAULT names HIP's legacy default stream, whose handle is also 0
+ * (torch's default stream): pass it when the render must be ordered against work queued there.   */
+#define PT_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1)
 int pt_context_set_stream(PtContext* ctx, void* hip_stream);
+int pt_context_set_tuning(PtContext* ctx, const PtTuning* tuning);
 
 /* Copy the scene to the device (the reference's World is immutable while
  * rendering: render_pixel(&self), src/world.rs:293).  Lights are detected as
  * in src/world.rs:214-225: objects whose emit() has non-zero length.          */
 int pt_scene_upload(PtContext* ctx, const PtObject* objs, uint32_t n_objs);
 
-/* Render the tile into DEVICE buffers (no host transfer inside):
+/* Render the tile into DEVICE buffers (no host transfer, no host synchronisation inside):
  *   d_linear_rgb: float[tile_rows*W*3], mean linear radiance  (= luminance_data,
  *                 src/world.rs:318-319)
  *   d_rgba8:      uint8[tile_rows*W*4], sqrt-gamma + truncation (= World.data /
  *                 draw(), src/world.rs:322-341); may be NULL.
- * Work is enqueued on the context's stream; the call returns once the last launch is
- * enqueued (it synchronises internally once per sample batch, where the tail of the
- * level-0 launch is handed to a continuation launch).  Renders of several sample batches
- * also use a second, context-owned stream for those tails; the context's stream waits
- * for it at the end, so everything is complete when that stream is.  pt_sync() waits.   */
+ * Work is enqueued on the context's stream and the call returns once the last launch is
+ * enqueued; the continuation launch that finishes the sparse tails of a sample batch takes
+ * its path count from device memory, so the host never waits inside.  Renders of several
+ * sample batches also use a second, context-owned stream for those tails; the context's
+ * stream waits for it at the end, so everything is complete when that stream is.  Once the
+ * buffers of a given size exist (after the first render of that size) the call allocates
+ * nothing and can be captured into a hipGraph.  pt_sync() waits.                          */
 int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
                      float* d_linear_rgb, uint8_t* d_rgba8);
 int pt_sync(PtContext* ctx);
@@ -208,9 +225,57 @@ int pt_render_progressive(PtContext* ctx, const PtCamera* cam, const PtRenderPar
                           float* out_linear_rgb, uint8_t* out_rgba8);
 
 /* One-shot convenience with HOST buffers: create context on device 0 (cached),
- * upload, render, copy back.  = everything src/main.rs:43-60 does.            */
+ * upload, render, copy back.  = everything src/main.rs:43-60 does.  params->n_devices > 1
+ * renders through pt_render_multi on devices 0 .. n_devices-1.  The cached contexts are freed
+ * by pt_shutdown() (also registered with atexit).                              */
 int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n_objs,
               const PtRenderParams* params, float* out_linear_rgb, uint8_t* out_rgba8);
+void pt_shutdown(void);
+
+/* ---- multi-GPU ------------------------------------------------
+ * ONE process drives n devices: one context per device, interleaved row bands (device g renders the bands b with
+ * b % n == g; pixels are independent units keyed by (x, y), src/main.rs:51, so there is no collective on the data
+ * path), and ONE RCCL gather (ncclGather, rccl.h:745, inside one ncclGroupStart/End) of the 16 B/pixel film tiles
+ * to the first device over xGMI.  The frame is bitwise independent of n.  RCCL is loaded with dlopen by
+ * pt_multi_create; hosts that render on one GPU never need it.  Not internally synchronised: one thread at a time. */
+typedef struct PtMulti PtMulti;
+int pt_multi_create(const int* devices, uint32_t n_devices, PtMulti** out);   /* contexts + ncclCommInitAll (rccl.h:236) */
+int pt_multi_destroy(PtMulti* m);
+uint32_t pt_multi_device_count(const PtMulti* m);
+int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs);  /* replicated on every device */
+/* Enqueue one frame: d_linear_rgb (H*W*3 floats) / d_rgba8 (H*W*4 bytes or NULL) are buffers on the FIRST device.
+ * params->band_rows = 0 picks about eight bands per device; band_index / band_count are ignored.            */
+int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams* params,
+                           float* d_linear_rgb, uint8_t* d_rgba8);
+int pt_multi_sync(PtMulti* m);
+int pt_multi_get_stats(PtMulti* m, PtStats* out);    /* counters summed over the devices, times of the slowest */
+int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* params,
+                         float* out_linear_rgb, uint8_t* out_rgba8);
+/* One shot with host buffers (a cached PtMulti for the device list; pt_shutdown frees it). */
+int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam, const PtObject* objs,
+                    uint32_t n_objs, const PtRenderParams* params, float* out_linear_rgb, uint8_t* out_rgba8);
+
+/* World::render_pixel (src/world.rs:293-333) -- the seam the reference's rayon loop calls at
+ * src/main.rs:55 -- for an arbitrary list of n pixels: xy = n * (x, y), y = film row (top-down, the y
+ * of the seed (y<<32)|x, main.rs:51).  Every listed pixel gets exactly the samples a full render gives
+ * it (same key, same sample indices spp_offset .. spp_offset+spp-1), so out_linear_rgb[3i..] /
+ * out_rgba8[4i..] are bit-identical to that pixel of the full film.  out_samples (optional,
+ * n * spp * 3 floats, [pixel][sample][rgb]) receives the radiance of every camera sample =
+ * RenderingStrategy::ray_color's return value (rendering.rs:34,214; what the reference's pixel
+ * diagnostics print, world.rs:378-417); it needs the whole list in one sample batch
+ * (n * spp <= max_paths_in_flight).  Host buffers, blocking.  band_* of params must select the
+ * whole image.                                                                                */
+int pt_render_pixels(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
+                     const uint32_t* xy, uint32_t n, float* out_linear_rgb, uint8_t* out_rgba8,
+                     float* out_samples);
+
+/* RenderingStrategy::ray_color(world, ray, depth = 0, rng, throughput = 1) (src/rendering.rs:34-142,
+ * 214-265) for n arbitrary rays: rays = n * (origin3, direction3), the direction is normalised on
+ * entry like Ray::new (camera.rs:10-16); xy = n * (x, y) = the RNG key of each ray's stream, and the
+ * sample index of every stream is params->spp_offset.  out_rgb = n * 3 floats.  Host buffers,
+ * blocking; the paths run through the same kernels as a render.                               */
+int pt_ray_color(PtContext* ctx, const PtRenderParams* params, const double* rays,
+                 const uint32_t* xy, uint32_t n, float* out_rgb);
 
 /* Debug/parity entry: closest-hit scan of World::hit_scene (src/world.rs:270-290)
  * on the device for n arbitrary rays (host arrays; rays = n*6 doubles o,d; the
@@ -219,6 +284,36 @@ int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n_objs,
 int pt_debug_hit_scene(PtContext* ctx, const double* rays, uint32_t n,
                        double t_min, double t_max, uint32_t exact_math, uint32_t accel,
                        int32_t* out_id, float* out_t);
+
+/* The same with the HitRecord of every hit (src/objects/base.rs:6-33): out_rec = n * 8 floats
+ * (t, point3, face-forwarded normal3, front_face as 0/1); zeros for a miss.   */
+int pt_debug_hit_records(PtContext* ctx, const double* rays, uint32_t n,
+                         double t_min, double t_max, uint32_t exact_math, uint32_t accel,
+                         int32_t* out_id, float* out_rec);
+
+/* Function-level parity entries: the per-vertex device functions of the path kernels on
+ * arbitrary inputs, one item per thread.  `obj` = index of an object of the uploaded scene.  Host arrays.
+ *   pt_debug_bsdf_eval     Material::bsdf_pdf (material.rs:86-91, 139-148, 221-265; mirror.rs:179-198)
+ *                          in = n * (ray dir3, wo3, normal3, ray.eta_ratio) -> out = n * (f3, pdf)
+ *   pt_debug_bsdf_sample   Material::bsdf_pdf_sample (material.rs:29-40; mirror.rs:200-305)
+ *                          in = n * (ray dir3, normal3, eta_ratio), words = n * 4 raw RNG words (r1, r2, lobe u, -)
+ *                          -> out = n * (wo3, f3, pdf, cos)
+ *   pt_debug_shape_sample  Shape::sample_surface_from_point (shape.rs:91-145, 200-242) of object obj from
+ *                          from3[i]; target3 != NULL: the look-ahead form (point given, no draws), else r12 =
+ *                          n * (r1, r2) uniforms -> out = n * (point3, pdf_omega, light_dir3, distance)
+ *   pt_debug_light_point   World::sample_light_point (world.rs:251-267) from from3[i]; words = n * 4
+ *                          (light-index word, r1 word, r2 word, -) -> out = n * (point3, emission3, pdf, light object)
+ *   pt_debug_camera_rays   Camera::get_ray_with_offset with the sample's own jitter draws (camera.rs:139-147,
+ *                          world.rs:299); xys = n * (x, y film row, sample) -> out = n * (origin3, direction3, ox, oy) */
+int pt_debug_bsdf_eval(PtContext* ctx, uint32_t obj, const double* in10, uint32_t n, uint32_t exact_math, float* out4);
+int pt_debug_bsdf_sample(PtContext* ctx, uint32_t obj, const double* in7, const uint32_t* words4, uint32_t n,
+                         uint32_t exact_math, float* out8);
+int pt_debug_shape_sample(PtContext* ctx, uint32_t obj, const double* from3, const double* target3, const double* r12,
+                          uint32_t n, uint32_t exact_math, float* out8);
+int pt_debug_light_point(PtContext* ctx, const double* from3, const uint32_t* words4, uint32_t n, uint32_t exact_math,
+                         float* out8);
+int pt_debug_camera_rays(PtContext* ctx, const PtCamera* cam, const uint32_t* xys, uint32_t n, uint32_t exact_math,
+                         float* out8);
 
 /* Debug entry, host only (no GPU needed): build the accel = 1 BVH of a scene and verify it -- every object in
  * exactly one leaf slot with its scan record, every child box encloses the boxes beneath it, depth within the

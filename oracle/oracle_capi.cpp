@@ -206,6 +206,55 @@ extern "C" void orc_bsdf_sample(const PtObject* po, int precision, const double*
     else bsdf_sample_batch<float>(po, in, draws, n, out);
 }
 
+// World::sample_light_point (world.rs:251-267) from n points: words n*4 = (light-index word, r1 word, r2 word, -);
+// out n*8 = point3, emission3, pdf, light object index (-1: the scene has no light).
+template <class R>
+static void light_point_batch(const PtObject* objs, uint32_t nobj, const double* from, const uint32_t* words, uint32_t n, double* out) {
+    Scene<R> sc = build_scene<R>(objs, nobj);
+    for (uint32_t i = 0; i < n; ++i) {
+        Hit<R> h; h.point = V3<R>((R)from[3 * i], (R)from[3 * i + 1], (R)from[3 * i + 2]);
+        LightSample<R> ls;
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, -1};
+        if (sample_light_point<R>(sc, h, words[4 * i], words[4 * i + 1], words[4 * i + 2], ls)) {
+            const uint32_t li = (uint32_t)(((uint64_t)words[4 * i] * sc.lights.size()) >> 32);
+            double w[8] = {ls.point.x, ls.point.y, ls.point.z, ls.emission.x, ls.emission.y, ls.emission.z, (double)ls.pdf,
+                           (double)sc.lights[li]};
+            std::memcpy(v, w, sizeof v);
+        }
+        std::memcpy(out + 8 * i, v, sizeof v);
+    }
+}
+extern "C" void orc_light_point(const PtObject* objs, uint32_t nobj, int precision, const double* from, const uint32_t* words,
+                                uint32_t n, double* out) {
+    if (precision == 64) light_point_batch<double>(objs, nobj, from, words, n, out);
+    else light_point_batch<float>(objs, nobj, from, words, n, out);
+}
+
+// RenderingStrategy::ray_color(world, ray, 0, rng, 1) (rendering.rs:34, 214) for n arbitrary rays: rays n*6 (Ray::new
+// normalises the direction), xy n*2 = RNG key of each ray's stream, `sample` = its sample index.  out n*3.
+template <class R>
+static void ray_color_batch(const PtObject* objs, uint32_t nobj, const PtRenderParams* pp, int form, const double* rays,
+                            const uint32_t* xy, uint32_t n, double* out) {
+    Scene<R> sc = build_scene<R>(objs, nobj);
+    Params prm = make_params(pp);
+    Counters cn;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double* r = rays + 6 * i;
+        Ray<R> ray(V3<R>((R)r[0], (R)r[1], (R)r[2]), V3<R>((R)r[3], (R)r[4], (R)r[5]));
+        Draws dr{{xy[2 * i], xy[2 * i + 1]}, pp->spp_offset};
+        V3<R> c;
+        if (form == FORM_ITERATIVE) c = ray_color_iter(sc, prm, ray, dr, cn);
+        else if (prm.integrator == PT_INTEGRATOR_MIS) c = ray_color_mis_rec(sc, prm, ray, 0, dr, V3<R>::one(), cn);
+        else c = ray_color_brdf_rec(sc, prm, ray, 0, dr, V3<R>::one(), cn);
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+}
+extern "C" void orc_ray_color(const PtObject* objs, uint32_t nobj, const PtRenderParams* pp, int precision, int form,
+                              const double* rays, const uint32_t* xy, uint32_t n, double* out) {
+    if (precision == 64) ray_color_batch<double>(objs, nobj, pp, form, rays, xy, n, out);
+    else ray_color_batch<float>(objs, nobj, pp, form, rays, xy, n, out);
+}
+
 // sin/cos(2*pi*u) in the given arithmetic mode (pins the f32 polynomial against libm).
 extern "C" void orc_sincos2pi(int precision, const double* u, uint32_t n, double* out_sc) {
     for (uint32_t i = 0; i < n; ++i) {

@@ -104,6 +104,25 @@ def bsdf_sample(obj_array, inp, draws, precision=F64):
     return out
 
 
+def light_point(objs, frm, words, precision=F64):
+    """World::sample_light_point: words n x 4 (index word, r1 word, r2 word, -) -> n x 8 = point3, emission3, pdf, light obj"""
+    frm = np.ascontiguousarray(frm, dtype=np.float64).reshape(-1, 3)
+    words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 4)
+    out = np.empty((frm.shape[0], 8), dtype=np.float64)
+    lib().orc_light_point(objs, C.c_uint32(len(objs)), C.c_int(precision), _p(frm), _p(words), C.c_uint32(frm.shape[0]), _p(out))
+    return out
+
+
+def ray_color(objs, params, rays, xy, precision=F64, form=RECURSIVE):
+    """RenderingStrategy::ray_color(world, ray, 0, rng(key xy, sample params.spp_offset), 1) -> n x 3"""
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+    out = np.empty((rays.shape[0], 3), dtype=np.float64)
+    lib().orc_ray_color(objs, C.c_uint32(len(objs)), C.byref(params), C.c_int(precision), C.c_int(form), _p(rays), _p(xy),
+                        C.c_uint32(rays.shape[0]), _p(out))
+    return out
+
+
 def sincos2pi(u, precision=F32):
     u = np.ascontiguousarray(u, dtype=np.float64)
     out = np.empty((u.shape[0], 2), dtype=np.float64)

@@ -5,5 +5,5 @@ Drop-in for the per-pixel rendering hot path of roxas1533/pathtrace
 (pathtrace_amd/csrc); this package is the ctypes harness tests and bench use.
 """
 from . import _lib, api  # noqa: F401
-from .api import (Context, builtin_scene, bvh_check, camera_look_at, camera_new, default_params, make_objects,  # noqa: F401
-                  render_host, tile_rows, tile_row_indices)
+from .api import (Context, Multi, builtin_scene, bvh_check, camera_look_at, camera_new, default_params, make_objects,  # noqa: F401
+                  render_host, render_multi, tile_rows, tile_row_indices)

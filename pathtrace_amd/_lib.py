@@ -48,6 +48,16 @@ class PtRenderParams(C.Structure):
         ("workgroups", C.c_uint32),
         ("exact_math", C.c_uint32),
         ("accel", C.c_uint32),
+        ("n_devices", C.c_uint32),
+    ]
+
+
+class PtTuning(C.Structure):
+    _fields_ = [
+        ("export_below", C.c_uint32),
+        ("bvh_refill", C.c_uint32),
+        ("bvh_leaf", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -72,6 +82,7 @@ class PtStats(C.Structure):
 PT_SHAPE_SPHERE, PT_SHAPE_TRIANGLE = 0, 1
 PT_MAT_LAMBERT, PT_MAT_EMISSIVE, PT_MAT_MIRROR, PT_MAT_OREN_NAYAR = 0, 1, 2, 3
 PT_INTEGRATOR_MIS, PT_INTEGRATOR_BRDF_ONLY = 0, 1
+PT_STREAM_LEGACY_DEFAULT = 1      # pt_context_set_stream: HIP's legacy default stream (handle 0 means "the context's own")
 
 # every symbol include/pathtrace_amd.h declares: name -> (restype, argtypes)
 _P = C.POINTER
@@ -85,6 +96,7 @@ SYMBOLS = {
     "pt_context_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
     "pt_context_destroy": (C.c_int, [C.c_void_p]),
     "pt_context_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_context_set_tuning": (C.c_int, [C.c_void_p, _P(PtTuning)]),
     "pt_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
     "pt_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_sync": (C.c_int, [C.c_void_p]),
@@ -95,7 +107,30 @@ SYMBOLS = {
     "pt_render": (C.c_int, [_P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_debug_hit_scene": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double, C.c_uint32,
                                      C.c_uint32, _P(C.c_int32), _P(C.c_float)]),
+    "pt_debug_hit_records": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_double, C.c_double, C.c_uint32,
+                                       C.c_uint32, _P(C.c_int32), _P(C.c_float)]),
+    "pt_debug_bsdf_eval": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_double), C.c_uint32, C.c_uint32, _P(C.c_float)]),
+    "pt_debug_bsdf_sample": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_double), _P(C.c_uint32), C.c_uint32, C.c_uint32,
+                                       _P(C.c_float)]),
+    "pt_debug_shape_sample": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_double), _P(C.c_double), _P(C.c_double), C.c_uint32,
+                                        C.c_uint32, _P(C.c_float)]),
+    "pt_debug_light_point": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint32), C.c_uint32, C.c_uint32, _P(C.c_float)]),
+    "pt_debug_camera_rays": (C.c_int, [C.c_void_p, _P(PtCamera), _P(C.c_uint32), C.c_uint32, C.c_uint32, _P(C.c_float)]),
     "pt_debug_bvh_check": (C.c_int, [_P(PtObject), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    "pt_render_pixels": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), _P(C.c_uint32), C.c_uint32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "pt_ray_color": (C.c_int, [C.c_void_p, _P(PtRenderParams), _P(C.c_double), _P(C.c_uint32), C.c_uint32, C.c_void_p]),
+    "pt_shutdown": (None, []),
+    "pt_multi_create": (C.c_int, [_P(C.c_int), C.c_uint32, _P(C.c_void_p)]),
+    "pt_multi_destroy": (C.c_int, [C.c_void_p]),
+    "pt_multi_device_count": (C.c_uint32, [C.c_void_p]),
+    "pt_multi_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
+    "pt_multi_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_multi_sync": (C.c_int, [C.c_void_p]),
+    "pt_multi_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
+    "pt_multi_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_render_multi": (C.c_int, [_P(C.c_int), C.c_uint32, _P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams),
+                                  C.c_void_p, C.c_void_p]),
     "pt_last_error": (C.c_char_p, []),
     "pt_abi_version": (C.c_uint32, []),
 }

@@ -99,7 +99,19 @@ class Context:
         check(lib().pt_scene_upload(self._h, objs, len(objs)))
 
     def set_stream(self, hip_stream_ptr):
-        check(lib().pt_context_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+        """Render on a caller-owned stream.  0 is the handle of HIP's legacy default stream (torch's default stream):
+        it is passed on as PT_STREAM_LEGACY_DEFAULT, so the render is ordered against the caller's other work there;
+        None restores the context's own stream."""
+        if hip_stream_ptr is None:
+            ptr = None
+        else:
+            ptr = C.c_void_p(hip_stream_ptr if hip_stream_ptr else _lib.PT_STREAM_LEGACY_DEFAULT)
+        check(lib().pt_context_set_stream(self._h, ptr))
+
+    def set_tuning(self, export_below=0, bvh_refill=0, bvh_leaf=0):
+        """Scheduling knobs (pt_context_set_tuning); 0 = library default.  Results never depend on them."""
+        t = _lib.PtTuning(export_below, bvh_refill, bvh_leaf, 0)
+        check(lib().pt_context_set_tuning(self._h, C.byref(t)))
 
     def render_into(self, cam, params, linear_ptr, rgba_ptr):
         """pt_render_device on raw device pointers (asynchronous; call sync())."""
@@ -149,6 +161,158 @@ class Context:
                                        ids.ctypes.data_as(C.POINTER(C.c_int32)),
                                        ts.ctypes.data_as(C.POINTER(C.c_float))))
         return ids, ts
+
+
+def _f64(a, cols):
+    return np.ascontiguousarray(a, dtype=np.float64).reshape(-1, cols)
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _pu(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32)) if a is not None else None
+
+
+def _pf(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class _ContextFunctions:
+    """Function-level entries of the C ABI (pt_debug_*, pt_render_pixels, pt_ray_color): the per-vertex device
+    functions on arbitrary inputs.  Mixed into Context."""
+
+    def debug_hit_records(self, rays, t_min=0.001, t_max=float("inf"), exact_math=0, accel=0):
+        """-> (ids int32[n], rec float32[n, 8] = t, point3, normal3, front_face)"""
+        rays = _f64(rays, 6)
+        n = rays.shape[0]
+        ids = np.empty(n, dtype=np.int32)
+        rec = np.empty((n, 8), dtype=np.float32)
+        check(lib().pt_debug_hit_records(self._h, _pd(rays), n, t_min, t_max, exact_math, accel,
+                                         ids.ctypes.data_as(C.POINTER(C.c_int32)), _pf(rec)))
+        return ids, rec
+
+    def debug_bsdf_eval(self, obj, inp, exact_math=0):
+        """inp n x (ray dir3, wo3, normal3, eta) -> float32[n, 4] = f3, pdf"""
+        inp = _f64(inp, 10)
+        out = np.empty((inp.shape[0], 4), dtype=np.float32)
+        check(lib().pt_debug_bsdf_eval(self._h, obj, _pd(inp), inp.shape[0], exact_math, _pf(out)))
+        return out
+
+    def debug_bsdf_sample(self, obj, inp, words, exact_math=0):
+        """inp n x (ray dir3, normal3, eta), words n x 4 raw u32 (r1, r2, lobe, -) -> float32[n, 8] = wo3, f3, pdf, cos"""
+        inp = _f64(inp, 7)
+        words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 4)
+        out = np.empty((inp.shape[0], 8), dtype=np.float32)
+        check(lib().pt_debug_bsdf_sample(self._h, obj, _pd(inp), _pu(words), inp.shape[0], exact_math, _pf(out)))
+        return out
+
+    def debug_shape_sample(self, obj, frm, target=None, r12=None, exact_math=0):
+        """-> float32[n, 8] = point3, pdf_omega, light_dir3, distance"""
+        frm = _f64(frm, 3)
+        tg = _f64(target, 3) if target is not None else None
+        rr = _f64(r12, 2) if r12 is not None else None
+        out = np.empty((frm.shape[0], 8), dtype=np.float32)
+        check(lib().pt_debug_shape_sample(self._h, obj, _pd(frm), _pd(tg), _pd(rr), frm.shape[0], exact_math, _pf(out)))
+        return out
+
+    def debug_light_point(self, frm, words, exact_math=0):
+        """World::sample_light_point: words n x 4 (index word, r1 word, r2 word, -) -> float32[n, 8] = point3, emission3,
+        pdf, light object"""
+        frm = _f64(frm, 3)
+        words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 4)
+        out = np.empty((frm.shape[0], 8), dtype=np.float32)
+        check(lib().pt_debug_light_point(self._h, _pd(frm), _pu(words), frm.shape[0], exact_math, _pf(out)))
+        return out
+
+    def debug_camera_rays(self, cam, xys, exact_math=0):
+        """xys n x (x, y film row, sample) -> float32[n, 8] = origin3, direction3, ox, oy"""
+        xys = np.ascontiguousarray(xys, dtype=np.uint32).reshape(-1, 3)
+        out = np.empty((xys.shape[0], 8), dtype=np.float32)
+        check(lib().pt_debug_camera_rays(self._h, C.byref(cam), _pu(xys), xys.shape[0], exact_math, _pf(out)))
+        return out
+
+    def render_pixels(self, cam, params, xy, want_samples=False):
+        """pt_render_pixels = World::render_pixel for a pixel list.  -> (linear f32[n,3], rgba u8[n,4], samples
+        f32[n,spp,3] or None)"""
+        xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+        n = xy.shape[0]
+        lin = np.empty((n, 3), dtype=np.float32)
+        rgba = np.empty((n, 4), dtype=np.uint8)
+        smp = np.empty((n, params.spp, 3), dtype=np.float32) if want_samples else None
+        check(lib().pt_render_pixels(self._h, C.byref(cam), C.byref(params), _pu(xy), n, lin.ctypes.data_as(C.c_void_p),
+                                     rgba.ctypes.data_as(C.c_void_p), smp.ctypes.data_as(C.c_void_p) if want_samples else None))
+        return lin, rgba, smp
+
+    def ray_color(self, params, rays, xy):
+        """pt_ray_color = RenderingStrategy::ray_color(world, ray, 0, rng(key xy, sample spp_offset), 1) -> f32[n,3]"""
+        rays = _f64(rays, 6)
+        xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+        assert xy.shape[0] == rays.shape[0]
+        out = np.empty((rays.shape[0], 3), dtype=np.float32)
+        check(lib().pt_ray_color(self._h, C.byref(params), _pd(rays), _pu(xy), rays.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+for _n, _f in vars(_ContextFunctions).items():
+    if not _n.startswith("__"):
+        setattr(Context, _n, _f)
+
+
+class Multi:
+    """pt_multi_*: ONE process, several GPUs, one RCCL gather of the film to the first device."""
+
+    def __init__(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        check(lib().pt_multi_create(arr, len(devices), C.byref(self._h)))
+        self.devices = list(devices)
+        self._objs = None
+
+    def close(self):
+        if self._h:
+            lib().pt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, objs):
+        self._objs = objs
+        check(lib().pt_multi_scene_upload(self._h, objs, len(objs)))
+
+    def render_into(self, cam, params, linear_ptr, rgba_ptr):
+        check(lib().pt_multi_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(linear_ptr),
+                                           C.c_void_p(rgba_ptr) if rgba_ptr else None))
+
+    def sync(self):
+        check(lib().pt_multi_sync(self._h))
+
+    def stats(self):
+        s = PtStats()
+        check(lib().pt_multi_get_stats(self._h, C.byref(s)))
+        return s
+
+    def render_host(self, cam, params):
+        lin = np.empty((cam.height, cam.width, 3), dtype=np.float32)
+        rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+        check(lib().pt_multi_render_host(self._h, C.byref(cam), C.byref(params), lin.ctypes.data_as(C.c_void_p),
+                                         rgba.ctypes.data_as(C.c_void_p)))
+        return lin, rgba
+
+
+def render_multi(devices, cam, objs, params):
+    """pt_render_multi: the one-shot multi-GPU entry with host buffers."""
+    arr = (C.c_int * len(devices))(*devices)
+    lin = np.empty((cam.height, cam.width, 3), dtype=np.float32)
+    rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+    check(lib().pt_render_multi(arr, len(devices), C.byref(cam), objs, len(objs), C.byref(params),
+                                lin.ctypes.data_as(C.c_void_p), rgba.ctypes.data_as(C.c_void_p)))
+    return lin, rgba
 
 
 def bvh_check(objs):

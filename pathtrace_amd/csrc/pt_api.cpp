@@ -21,9 +21,9 @@
 #include "pt_bvh.h"
 #include "pt_kernels.h"
 
+static thread_local std::string g_err;
 namespace {
 
-thread_local std::string g_err;
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -67,6 +67,8 @@ constexpr uint32_t kMinGrid = 256 * 8;         // level-0 launches: at least thi
 // continuation launches: one resident round at 6 waves/SIMD.  Their paths are sparse survivors; more, emptier
 // segments cost lane utilisation (measured on C2, ms per step: 1536 -> 9.40, 2048 -> 9.47, 3072 -> 9.69, 6144 -> 10.18)
 constexpr uint32_t kContGrid = 256 * 6;
+constexpr uint32_t kExportSmall = 64;          // a wave hands its segment over when fewer paths than this are left
+                                               // (measured 32 ... 256: no difference beyond noise on C1 and C2)
 // Tail hand-off: in launches of more than kExportMinPaths paths a wave whose segment falls below one chunk
 // exports its leftovers to the overflow queue instead of walking them alone; the next launch takes them up.
 // Measured (C2 / C1 ms per 1024^2 x 64 render): no hand-off 10.33 / 18.5; threshold 2^18 (3-4 levels) 11.2 / 16.9;
@@ -82,6 +84,18 @@ constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
 constexpr uint32_t kAutoBvhWeight = 512;
 
 }  // namespace
+
+// shared with pt_multi.cpp
+int pt_internal_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+void pt_internal_multi_shutdown(void);
 
 struct PtContext {
     int device = 0;
@@ -127,12 +141,30 @@ struct PtContext {
     bool stats_pending = false;
     uint32_t profiled_batches = 0;
     std::vector<uint32_t> primary_events;      // launch indices of the level-0 launches
-    // progressive rendering (pt_render_progressive): carry the f64 film sums across calls
-    bool prog_load = false, prog_store = false;
-    uint32_t prog_div = 0;
+    PtTuning tuning{};                         // pt_context_set_tuning; 0 = library default
+    bool bvh_failed = false;                   // the BVH builder refused this scene (depth): PT_ACCEL_AUTO stays with the scan
+    // pixel-list entries (pt_render_pixels, pt_ray_color)
+    DevBuf<uint2> pixel_list;
+    DevBuf<float4> inject[4];
+    DevBuf<float> fn_in, fn_out;               // pt_debug_* function entries
+    DevBuf<uint32_t> fn_words;
 };
 
 namespace {
+
+// What a render does with the f64 film sums (pt_render_progressive carries them across calls).
+struct FilmState {
+    bool load = false;        // start from the sums in c->film
+    bool store = false;       // keep the sums (more samples follow in a later call)
+    uint32_t div = 0;         // samples the mean is taken over (0: this call's spp)
+};
+// Pixel-list render: film slot i <-> image pixel d_pixels[i]; inject: the paths are given (pt_ray_color) instead of
+// generated by the camera.
+struct ListRender {
+    const uint2* d_pixels = nullptr;
+    uint32_t n = 0;
+    const float4* inject[4] = {nullptr, nullptr, nullptr, nullptr};
+};
 
 int ensure_events(PtContext* c, size_t n) {
     while (c->ev_pool.size() < n) {
@@ -179,6 +211,7 @@ void shape_records(const PtObject& o, float4 gather[3], float4 scan[3], int* n_s
 int ensure_bvh(PtContext* c) {
     if (c->has_bvh) return PT_OK;
     if (c->bvh_refused) return fail(PT_ERR_UNSUPPORTED, "accel: the scene has object(s) with a NaN/inf coordinate; use the linear scan");
+    if (c->bvh_failed) return fail(PT_ERR_UNSUPPORTED, "accel: the BVH of this scene is deeper than the traversal stack; use the linear scan");
     if (c->view.n_objs >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "accel: %u objects exceed the 2^28 leaf slots", c->view.n_objs);
     ptbvh::Built b = ptbvh::build(c->h_shape.data(), c->h_shape_tag.data(), c->view.n_objs);
     static_assert(ptbvh::kStackDepth == ptk::kBvhStack, "traversal stack depth");
@@ -188,7 +221,10 @@ int ensure_bvh(PtContext* c) {
         return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate; the linear scan's answer for them "
                                         "depends on the scan order, use the linear scan", b.non_finite);
     }
-    if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
+    if (b.depth + 2u > ptbvh::kStackDepth) {
+        c->bvh_failed = true;        // a property of the scene: do not rebuild on every render
+        return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
+    }
     int rc;
     if ((rc = c->bvh_nodes.ensure(b.nodes.size() + 4)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
         (rc = c->bvh_ids.ensure(b.leaf_ids.size() + 1)))
@@ -227,6 +263,7 @@ void pt_default_params(PtRenderParams* p) {
     p->max_paths_in_flight = 0;
     p->profile = 0;
     p->accel = PT_ACCEL_AUTO;
+    p->n_devices = 1;
 }
 
 uint32_t pt_tile_rows(uint32_t height, uint32_t band_rows, uint32_t band_index, uint32_t band_count) {
@@ -291,6 +328,8 @@ int pt_context_destroy(PtContext* c) {
     c->ovf_count.release();
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     c->lsamp.release(); c->dstats.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
+    c->pixel_list.release(); c->fn_in.release(); c->fn_out.release(); c->fn_words.release();
+    for (auto& b : c->inject) b.release();
     if (c->h_dstats) (void)hipHostFree(c->h_dstats);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -302,7 +341,14 @@ int pt_context_destroy(PtContext* c) {
 
 int pt_context_set_stream(PtContext* c, void* hip_stream) {
     if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (hip_stream == PT_STREAM_LEGACY_DEFAULT) c->stream = nullptr;      // HIP's legacy default stream (handle 0)
+    else c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PT_OK;
+}
+
+int pt_context_set_tuning(PtContext* c, const PtTuning* t) {
+    if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
+    c->tuning = t ? *t : PtTuning{};
     return PT_OK;
 }
 
@@ -389,6 +435,7 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     c->view.bvh = ptk::BvhView{};
     c->has_bvh = false;
     c->bvh_refused = false;
+    c->bvh_failed = false;
     {
         uint64_t tris = 0;
         for (uint32_t i = 0; i < n; ++i) tris += objs[i].shape_tag == PT_SHAPE_TRIANGLE;
@@ -401,52 +448,63 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     return PT_OK;
 }
 
-int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* d_linear, uint8_t* d_rgba) {
-    if (!c || !cam || !prm) return fail(PT_ERR_INVALID_ARG, "pt_render_device: null argument");
-    if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "pt_render_device: no scene uploaded");
-    if (cam->width < 2 || cam->height < 2)   // get_ray_with_offset divides by width-1 / height-1 (camera.rs:140-141)
+}  // extern "C"
+
+namespace {
+
+// The render driver behind every rendering entry: everything src/main.rs:43-60 does for the tile (or, with `list`,
+// for a pixel list / a set of given rays).  Enqueues on the context's streams and returns; no host synchronisation.
+int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, const FilmState& fs, const ListRender* list,
+                float* d_linear, uint8_t* d_rgba) {
+    if (!c || !cam || !prm) return fail(PT_ERR_INVALID_ARG, "render: null argument");
+    if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "render: no scene uploaded");
+    const bool inject = list && list->inject[0];
+    if (!inject && (cam->width < 2 || cam->height < 2))   // get_ray_with_offset divides by width-1 / height-1 (camera.rs:140-141)
         return fail(PT_ERR_INVALID_ARG, "camera %ux%u: width and height must be >= 2", cam->width, cam->height);
     if (prm->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
     if (prm->integrator > PT_INTEGRATOR_BRDF_ONLY) return fail(PT_ERR_INVALID_ARG, "unknown integrator %u", prm->integrator);
     if (prm->accel > PT_ACCEL_AUTO) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", prm->accel);
     const uint32_t band_count = prm->band_count ? prm->band_count : 1;
     if (prm->band_index >= band_count) return fail(PT_ERR_INVALID_ARG, "band_index %u >= band_count %u", prm->band_index, band_count);
+    if (list && band_count != 1) return fail(PT_ERR_INVALID_ARG, "pixel-list renders take the whole image (band_count = 1)");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     PtRenderParams resolved = *prm;      // PT_ACCEL_AUTO -> what actually runs
     if (prm->accel == PT_ACCEL_AUTO) {
         resolved.accel = PT_ACCEL_LINEAR;
-        if (c->auto_bvh && !c->bvh_refused && ensure_bvh(c) == PT_OK) resolved.accel = PT_ACCEL_BVH;
+        if (c->auto_bvh && !c->bvh_refused && !c->bvh_failed) {
+            const std::string keep = g_err;              // a refused BVH is not an error of this call
+            if (ensure_bvh(c) == PT_OK) resolved.accel = PT_ACCEL_BVH;
+            else g_err = keep;
+        }
     }
     prm = &resolved;
 
-    std::vector<uint32_t> rows = tile_row_list(cam->height, prm->band_rows, prm->band_index, band_count);
-    const uint64_t np64 = (uint64_t)rows.size() * cam->width;
+    const uint64_t np64 = list ? list->n : (uint64_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
+    const uint64_t tile_rows = list ? ((np64 + 65535u) >> 16) : np64 / cam->width;
     std::memset(&c->stats, 0, sizeof c->stats);
     if (np64 == 0) return PT_OK;   // empty tile: nothing to render
-    if (!d_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_device: d_linear_rgb is null");
-    if (cam->width > 65535u || rows.size() > 65535u)   // (tile row, x) share one word of the path state
-        return fail(PT_ERR_UNSUPPORTED, "tile %ux%zu: width and tile rows must be < 65536", cam->width, rows.size());
+    if (!d_linear) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer is null");
+    if (!list && (cam->width > 65535u || tile_rows > 65535u))   // (tile row, x) share one word of the path state
+        return fail(PT_ERR_UNSUPPORTED, "tile %ux%llu: width and tile rows must be < 65536", cam->width, (unsigned long long)tile_rows);
     uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : kDefaultMaxPaths;
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)
         return fail(PT_ERR_UNSUPPORTED, "tile of %llu pixels exceeds max_paths_in_flight %llu; use more bands",
                     (unsigned long long)np64, (unsigned long long)cap);
     const uint32_t np = (uint32_t)np64;
-    uint32_t nb_max = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(cap / np, 65535u), prm->spp);
+    const uint32_t spp = inject ? 1u : prm->spp;
+    uint32_t nb_max = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(cap / np, 65535u), spp);
     if (nb_max == 0) nb_max = 1;
     const size_t n_paths_max = (size_t)np * nb_max;
-    const uint32_t n_batches = (prm->spp + nb_max - 1) / nb_max;
+    const uint32_t n_batches = (spp + nb_max - 1) / nb_max;
 
-    // Queue segments: one per wave of the (fixed) bounce grid; bounce 0 deals 64-path
-    // chunks round-robin, so a segment holds at most ceil(chunks / waves) chunks.
-    // a wave hands its segment over when fewer paths than this are left (measured 32 ... 256: no difference beyond
-    // noise on C1 and C2 at ~672 paths per wave; one chunk it is)
-    uint32_t export_small = 64u;
-    if (const char* e = std::getenv("PT_EXPORT_BELOW")) export_small = (uint32_t)std::min(256, std::max(1, std::atoi(e)));   // tuning knob
-    const uint32_t grid_env = prm->workgroups;
+    // Queue segments: one per wave of the (fixed) grid; pass 0 deals 64-path chunks round-robin, so a segment holds
+    // at most ceil(chunks / waves) chunks.
+    const uint32_t export_small = c->tuning.export_below ? std::min(256u, std::max(1u, c->tuning.export_below)) : kExportSmall;
     const uint32_t chunks_max = (uint32_t)((n_paths_max + 63) / 64);
-    uint32_t grid = grid_env;
+    uint32_t grid = prm->workgroups;
+    const bool small_scene = c->view.n_objs <= ptk::kSmallObjs || prm->accel;     // the tiled scan exports per workgroup (< 256 paths)
     const uint32_t paths_per_wave = (c->view.n_objs <= ptk::kSmallObjs && !prm->accel) ? kPathsPerWaveLds : kPathsPerWave;
     if (!grid) {
         const uint64_t want = (n_paths_max + (uint64_t)paths_per_wave * kWavesPerBlock - 1) / ((uint64_t)paths_per_wave * kWavesPerBlock);
@@ -456,17 +514,17 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     if (grid == 0) grid = 1;
     const uint32_t nw = grid * kWavesPerBlock;
     const uint32_t seg_cap = ((chunks_max + nw - 1) / nw) * 64u;
-    const bool hand_off = true;
-    const bool small_scene = c->view.n_objs <= ptk::kSmallObjs || prm->accel;     // the tiled scan exports per workgroup (< 256 paths)
-    const uint32_t nw_cont = std::max(nw, kMinGrid * kWavesPerBlock);    // waves of any continuation launch
-    // leftovers per wave of a launch: < export_small from a wave-private segment, < 256 per workgroup (= 64 per wave)
-    // from a workgroup-shared one
-    const uint32_t export_max = std::max(export_small, 64u);
-    const size_t ovf_slots = (size_t)nw_cont * export_max;
-    // level 0 needs nw*seg_cap slots; a continuation launch of n < nw*export_max paths needs <= n + 64 + nw_cont*64
-    const size_t q_slots_cont = (size_t)nw * export_max + 64u + (size_t)nw_cont * 64u;
+    // Tail hand-off: the level-0 launch of a large batch exports what its waves have left below one chunk; ONE
+    // continuation launch of fixed size takes that queue up.  It reads the count on the device.
+    const bool hand_off = !inject && n_paths_max > kExportMinPaths;
+    const uint32_t nw_cont = kContGrid * kWavesPerBlock;
+    // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup
+    // (= 64 per wave) from a workgroup-shared one
+    const size_t ovf_slots = (size_t)nw * std::max(export_small, 64u) + 64u;
+    const uint32_t seg_cap_cont = (uint32_t)((((ovf_slots + 63) / 64 + nw_cont - 1) / nw_cont) * 64u);
+    const size_t q_slots_cont = hand_off ? (size_t)nw_cont * seg_cap_cont : 0;
     const size_t q_slots = std::max((size_t)nw * seg_cap, q_slots_cont);
-    // Multi-batch renders overlap the tail of batch k (continuation launches, resolve) with the body of batch k + 1
+    // Multi-batch renders overlap the tail of batch k (continuation launch, resolve) with the body of batch k + 1
     const bool overlap = n_batches > 1;
 
     int rc;
@@ -478,25 +536,23 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
-    if (overlap)
+    if (overlap && hand_off)
         for (int k = 0; k < 4; ++k)
             if ((rc = c->cqueue[k].ensure(q_slots_cont))) return rc;
-    if (overlap && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
-                                  (rc = c->csray[1].ensure(q_slots_cont))))
+    if (overlap && hand_off && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
+                                              (rc = c->csray[1].ensure(q_slots_cont))))
         return rc;
     if ((rc = c->ovf_count.ensure(4))) return rc;
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
-            for (int b = 0; b < 2; ++b)
-                for (int k = 0; k < 4; ++k)
-                    if ((rc = c->ovf[par][b][k].ensure(ovf_slots))) return rc;
+            for (int k = 0; k < 4; ++k)
+                if ((rc = c->ovf[par][0][k].ensure(ovf_slots))) return rc;
     if ((rc = c->dstats.ensure(8))) return rc;
-    if ((n_batches > 1 || c->prog_load || c->prog_store) && (rc = c->film.ensure((size_t)np * 3))) return rc;
+    if ((n_batches > 1 || fs.load || fs.store) && (rc = c->film.ensure((size_t)np * 3))) return rc;
 
     ptk::BounceArgs a{};
-    a.seg_cap = seg_cap;
     a.stats = c->dstats.p;
-    {   // tile row -> image row without a table (ptk::TileMap)
+    if (!list) {   // tile row -> image row without a table (ptk::TileMap)
         const uint32_t br = prm->band_rows ? prm->band_rows : cam->height;
         a.tile.band_rows = br;
         a.tile.band_magic = br > 1 ? (uint32_t)(((1ull << 32) + br - 1) / br) : 0u;
@@ -509,16 +565,15 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         a.cam.horizontal[k] = (float)cam->horizontal[k]; a.cam.vertical[k] = (float)cam->vertical[k];
     }
     a.cam.width = cam->width; a.cam.height = cam->height;
+    a.pixels = list ? list->d_pixels : nullptr;
+    a.film_w = list ? 65536u : cam->width;
     a.np = np;
     a.min_depth = prm->min_depth; a.max_depth = prm->max_depth;
     a.t_min = (float)prm->t_min;
     a.integrator = prm->integrator;
     a.accel = prm->accel;
-    a.bvh_refill = ptk::kRefillBelow; a.bvh_leaf = ptk::kLeafBatch;
-    if (const char* e = std::getenv("PT_BVH_REFILL")) a.bvh_refill = (uint32_t)std::atoi(e);     // tuning knobs, results do not depend on them
-    if (const char* e = std::getenv("PT_BVH_LEAF")) a.bvh_leaf = (uint32_t)std::atoi(e);
-    if (a.bvh_refill < 1u) a.bvh_refill = 1u;
-    if (a.bvh_refill > 64u) a.bvh_refill = 64u;
+    a.bvh_refill = c->tuning.bvh_refill ? std::min(64u, c->tuning.bvh_refill) : ptk::kRefillBelow;
+    a.bvh_leaf = c->tuning.bvh_leaf ? c->tuning.bvh_leaf : ptk::kLeafBatch;
 
     const bool profile = prm->profile != 0;
     HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
@@ -533,41 +588,42 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     }
     for (uint32_t batch = 0; batch < n_batches; ++batch) {
         const uint32_t s0 = batch * nb_max;
-        const uint32_t nb = std::min(nb_max, prm->spp - s0);
+        const uint32_t nb = std::min(nb_max, spp - s0);
         const int par = overlap ? (int)(batch & 1u) : 0;          // buffers of this batch
         float4* const lsamp_b = par ? c->lsamp2.p : c->lsamp.p;
         a.s_base = prm->spp_offset + s0;
         a.lsamp = lsamp_b;
-        // batch k reuses the sample buffer and overflow queues of batch k - 2: wait until its tail is through
+        // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
         if (overlap && batch >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[par], 0));
-        // Level 0 traces the batch's paths (every bounce, see k_paths); waves hand their sparse tails to the
-        // overflow queue, which the next level consumes densely, until a level is small enough to finish alone.
-        uint32_t n_level = np * nb;
-        for (uint32_t level = 0; n_level != 0u; ++level) {
+        uint32_t* const d_count = c->ovf_count.p + par;
+        // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
+        // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
+        for (uint32_t level = 0; level < (hand_off ? 2u : 1u); ++level) {
             hipStream_t ls = level == 0 ? st : side;
-            const uint32_t chunks = (n_level + 63u) / 64u;
+            const bool own = overlap && level > 0;       // continuation launch of an overlapped batch: its own queue
             uint32_t g = grid;
+            a.n_first = np * nb;
+            a.n_first_dev = nullptr;
+            a.seg_cap = ((((a.n_first + 63u) / 64u) + nw - 1) / nw) * 64u;
+            a.src_mode = inject ? 1u : 0u;
+            a.export_below = hand_off ? (small_scene ? export_small : ptk::kBlock) : 1u;
             if (level > 0) {
-                const uint64_t want = ((uint64_t)n_level + (uint64_t)paths_per_wave * kWavesPerBlock - 1) / ((uint64_t)paths_per_wave * kWavesPerBlock);
-                g = (uint32_t)std::max<uint64_t>(want, kContGrid);
-                g = std::min<uint32_t>(g, (chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+                g = kContGrid;
+                a.n_first = 0; a.n_first_dev = d_count;
+                a.seg_cap = seg_cap_cont;
+                a.src_mode = 1u;
+                a.export_below = 1u;
             }
-            const uint32_t nw_l = g * kWavesPerBlock;
-            a.n_first = n_level;
-            a.seg_cap = ((chunks + nw_l - 1) / nw_l) * 64u;
-            a.src_mode = level > 0 ? 1u : 0u;
-            a.export_below = (hand_off && n_level > kExportMinPaths) ? (small_scene ? export_small : ptk::kBlock) : 1u;
-            const bool own = overlap && level > 0;       // continuation launches of an overlapped batch: their own queue
             a.aux = own ? c->caux.p : c->bvh_aux.p;
             a.sray0 = own ? c->csray[0].p : c->bvh_sray[0].p;
             a.sray1 = own ? c->csray[1].p : c->bvh_sray[1].p;
             for (int k = 0; k < 4; ++k) {
                 a.q.q[k] = own ? c->cqueue[k].p : c->queue[k].p;
-                a.ovf_out.q[k] = hand_off ? c->ovf[par][level & 1][k].p : nullptr;
-                a.ovf_in.q[k] = hand_off ? c->ovf[par][(level + 1) & 1][k].p : nullptr;
+                a.ovf_out.q[k] = hand_off ? c->ovf[par][0][k].p : nullptr;
+                a.ovf_in.q[k] = inject ? const_cast<float4*>(list->inject[k]) : (hand_off ? c->ovf[par][0][k].p : nullptr);
             }
-            a.ovf_out_count = c->ovf_count.p + 2 * par + (level & 1);
-            if (a.export_below > 1u) HIP_TRY(hipMemsetAsync(a.ovf_out_count, 0, sizeof(uint32_t), ls));
+            a.ovf_out_count = d_count;
+            if (level == 0 && hand_off) HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), ls));
             if (profile) {
                 if ((rc = ensure_events(c, 2 * (size_t)(launches + 1)))) return rc;
                 HIP_TRY(hipEventRecord(c->ev_pool[2 * launches], ls));
@@ -578,12 +634,6 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
             HIP_TRY(hipGetLastError());
             if (level == 0) c->primary_events.push_back(launches);
             ++launches;
-            n_level = 0;
-            if (a.export_below > 1u) {       // how many paths were handed off?
-                HIP_TRY(hipMemcpyAsync(c->h_ovf, a.ovf_out_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
-                HIP_TRY(hipStreamSynchronize(ls));
-                n_level = c->h_ovf[0];
-            }
             if (overlap && level == 0) {     // the tail of this batch (side stream) starts when its level-0 launch is through
                 HIP_TRY(hipEventRecord(c->ev_l0[par], st));
                 HIP_TRY(hipStreamWaitEvent(side, c->ev_l0[par], 0));
@@ -595,10 +645,10 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         r.out_linear = d_linear;
         r.out_rgba = d_rgba;
         r.np = np; r.nb = nb;
-        r.load_film = batch > 0 || c->prog_load;
-        r.store_film = batch + 1 < n_batches || c->prog_store;
+        r.load_film = batch > 0 || fs.load;
+        r.store_film = batch + 1 < n_batches || fs.store;
         r.finalize = batch + 1 == n_batches;
-        r.spp_div = c->prog_div ? c->prog_div : prm->spp;
+        r.spp_div = fs.div ? fs.div : spp;
         ptk::launch_resolve(r, side);
         HIP_TRY(hipGetLastError());
         if (overlap) HIP_TRY(hipEventRecord(c->ev_resolved[par], side));
@@ -607,7 +657,7 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
         HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
     HIP_TRY(hipEventRecord(c->ev_end, st));
     HIP_TRY(hipMemcpyAsync(c->h_dstats, c->dstats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    c->stats.samples = (uint64_t)np * prm->spp;
+    c->stats.samples = (uint64_t)np * spp;
     c->stats.bounce_launches = launches;
     c->stats.batches = n_batches;
     c->stats.primary_launches = (uint32_t)c->primary_events.size();
@@ -616,6 +666,18 @@ int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     c->stats_pending = true;
     return PT_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* d_linear, uint8_t* d_rgba) {
+    return render_impl(c, cam, prm, FilmState{}, nullptr, d_linear, d_rgba);
+}
+
+}  // extern "C"
+hipStream_t pt_internal_stream(PtContext* c) { return c->stream; }
+extern "C" {
 
 int pt_sync(PtContext* c) {
     if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
@@ -650,33 +712,130 @@ int pt_get_stats(PtContext* c, PtStats* out) {
     return PT_OK;
 }
 
-int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, uint32_t exact_math,
-                       uint32_t accel, int32_t* out_id, float* out_t) {
-    if (!c || !rays || !out_id || !out_t) return fail(PT_ERR_INVALID_ARG, "null argument");
+}  // extern "C"
+
+namespace {
+
+int debug_hit_impl(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, uint32_t exact_math,
+                   uint32_t accel, int32_t* out_id, float* out_t, float* out_rec) {
+    if (!c || !rays || !out_id) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
     if (accel > PT_ACCEL_AUTO) return fail(PT_ERR_INVALID_ARG, "unknown accel %u", accel);
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (accel == PT_ACCEL_AUTO) accel = (c->auto_bvh && !c->bvh_refused && ensure_bvh(c) == PT_OK) ? PT_ACCEL_BVH : PT_ACCEL_LINEAR;
+    if (accel == PT_ACCEL_AUTO) {
+        const std::string keep = g_err;
+        accel = (c->auto_bvh && !c->bvh_refused && !c->bvh_failed && ensure_bvh(c) == PT_OK) ? PT_ACCEL_BVH : PT_ACCEL_LINEAR;
+        if (!accel) g_err = keep;
+    }
     if (accel) { int rb = ensure_bvh(c); if (rb) return rb; }
     std::vector<float> r6(6 * (size_t)n);
     for (size_t i = 0; i < r6.size(); ++i) r6[i] = (float)rays[i];
-    DevBuf<float> d_r, d_t;
+    DevBuf<float> d_r, d_t, d_rec;
     DevBuf<int32_t> d_id;
     DevBuf<float4> d_scratch;
-    struct Release { DevBuf<float>&a, &b; DevBuf<int32_t>& c; DevBuf<float4>& d; ~Release() { a.release(); b.release(); c.release(); d.release(); } }
-        guard{d_r, d_t, d_id, d_scratch};
+    struct Release { DevBuf<float>&a, &b, &e; DevBuf<int32_t>& c; DevBuf<float4>& d; ~Release() { a.release(); b.release(); e.release(); c.release(); d.release(); } }
+        guard{d_r, d_t, d_rec, d_id, d_scratch};
     int rc;
     if ((rc = d_r.ensure(r6.size())) || (rc = d_id.ensure(n)) || (rc = d_t.ensure(n))) return rc;
+    if (out_rec && (rc = d_rec.ensure(8 * (size_t)n))) return rc;
     if (accel && (rc = d_scratch.ensure(3 * (size_t)n))) return rc;
     HIP_TRY(hipMemcpy(d_r.p, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (exact_math) ptk::launch_debug_hit_exact(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, c->stream);
-    else ptk::launch_debug_hit_fast(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, c->stream);
+    if (exact_math) ptk::launch_debug_hit_exact(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, d_rec.p, c->stream);
+    else ptk::launch_debug_hit_fast(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, d_rec.p, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out_id, d_id.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_t) HIP_TRY(hipMemcpy(out_t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_rec) HIP_TRY(hipMemcpy(out_rec, d_rec.p, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+// One launch of k_debug_fn: in = n * in_stride floats (host), words = n * 4 raw words or null, out = n * out_stride floats.
+int debug_fn(PtContext* c, uint32_t op, uint32_t obj, const std::vector<float>& in, uint32_t in_stride, const uint32_t* words,
+             uint32_t n, uint32_t out_stride, uint32_t exact_math, const PtCamera* cam, float* out) {
+    if (!c || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
+    if (op != ptk::kFnLightPoint && op != ptk::kFnCameraRay && obj >= c->view.n_objs)
+        return fail(PT_ERR_INVALID_ARG, "object %u out of range (%u objects)", obj, c->view.n_objs);
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->fn_in.ensure(in.size() + 1)) || (rc = c->fn_out.ensure((size_t)n * out_stride)) ||
+        (rc = c->fn_words.ensure(4 * (size_t)n)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!in.empty()) HIP_TRY(hipMemcpy(c->fn_in.p, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (words) HIP_TRY(hipMemcpy(c->fn_words.p, words, 4 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ptk::DebugFnArgs a{};
+    a.sc = c->view;
+    if (cam) {
+        for (int k = 0; k < 3; ++k) {
+            a.cam.origin[k] = (float)cam->origin[k]; a.cam.lower_left[k] = (float)cam->lower_left[k];
+            a.cam.horizontal[k] = (float)cam->horizontal[k]; a.cam.vertical[k] = (float)cam->vertical[k];
+        }
+        a.cam.width = cam->width; a.cam.height = cam->height;
+    }
+    a.op = op; a.obj = obj; a.n = n; a.in_stride = in_stride; a.out_stride = out_stride;
+    a.in = c->fn_in.p; a.words = words ? c->fn_words.p : nullptr; a.out = c->fn_out.p;
+    if (exact_math) ptk::launch_debug_fn_exact(a, c->stream); else ptk::launch_debug_fn_fast(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->fn_out.p, (size_t)n * out_stride * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+std::vector<float> to_f32(const double* p, size_t n) {
+    std::vector<float> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (float)p[i];
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_debug_hit_scene(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, uint32_t exact_math,
+                       uint32_t accel, int32_t* out_id, float* out_t) {
+    if (!out_t) return fail(PT_ERR_INVALID_ARG, "null argument");
+    return debug_hit_impl(c, rays, n, t_min, t_max, exact_math, accel, out_id, out_t, nullptr);
+}
+int pt_debug_hit_records(PtContext* c, const double* rays, uint32_t n, double t_min, double t_max, uint32_t exact_math,
+                         uint32_t accel, int32_t* out_id, float* out_rec) {
+    if (!out_rec) return fail(PT_ERR_INVALID_ARG, "null argument");
+    return debug_hit_impl(c, rays, n, t_min, t_max, exact_math, accel, out_id, nullptr, out_rec);
+}
+
+int pt_debug_bsdf_eval(PtContext* c, uint32_t obj, const double* in10, uint32_t n, uint32_t exact_math, float* out4) {
+    if (!in10 && n) return fail(PT_ERR_INVALID_ARG, "null argument");
+    return debug_fn(c, ptk::kFnBsdfEval, obj, to_f32(in10, 10 * (size_t)n), 10, nullptr, n, 4, exact_math, nullptr, out4);
+}
+int pt_debug_bsdf_sample(PtContext* c, uint32_t obj, const double* in7, const uint32_t* words4, uint32_t n,
+                         uint32_t exact_math, float* out8) {
+    if ((!in7 || !words4) && n) return fail(PT_ERR_INVALID_ARG, "null argument");
+    return debug_fn(c, ptk::kFnBsdfSample, obj, to_f32(in7, 7 * (size_t)n), 7, words4, n, 8, exact_math, nullptr, out8);
+}
+int pt_debug_shape_sample(PtContext* c, uint32_t obj, const double* from3, const double* target3, const double* r12,
+                          uint32_t n, uint32_t exact_math, float* out8) {
+    if ((!from3 || (!target3 && !r12)) && n) return fail(PT_ERR_INVALID_ARG, "null argument");
+    std::vector<float> in(9 * (size_t)n, 0.0f);
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) in[9 * i + k] = (float)from3[3 * i + k];
+        if (target3) { for (int k = 0; k < 3; ++k) in[9 * i + 3 + k] = (float)target3[3 * i + k]; in[9 * i + 8] = 1.0f; }
+        else { in[9 * i + 6] = (float)r12[2 * i]; in[9 * i + 7] = (float)r12[2 * i + 1]; }
+    }
+    return debug_fn(c, ptk::kFnShapeSample, obj, in, 9, nullptr, n, 8, exact_math, nullptr, out8);
+}
+int pt_debug_light_point(PtContext* c, const double* from3, const uint32_t* words4, uint32_t n, uint32_t exact_math,
+                         float* out8) {
+    if ((!from3 || !words4) && n) return fail(PT_ERR_INVALID_ARG, "null argument");
+    return debug_fn(c, ptk::kFnLightPoint, 0, to_f32(from3, 3 * (size_t)n), 3, words4, n, 8, exact_math, nullptr, out8);
+}
+int pt_debug_camera_rays(PtContext* c, const PtCamera* cam, const uint32_t* xys, uint32_t n, uint32_t exact_math, float* out8) {
+    if ((!cam || !xys) && n) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (cam && (cam->width < 2 || cam->height < 2)) return fail(PT_ERR_INVALID_ARG, "camera %ux%u: width and height must be >= 2", cam->width, cam->height);
+    std::vector<uint32_t> w(4 * (size_t)n, 0u);
+    for (size_t i = 0; i < n; ++i) { w[4 * i] = xys[3 * i]; w[4 * i + 1] = xys[3 * i + 1]; w[4 * i + 2] = xys[3 * i + 2]; }
+    return debug_fn(c, ptk::kFnCameraRay, 0, std::vector<float>(), 1, w.data(), n, 8, exact_math, cam, out8);
 }
 
 int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32_t* n_nodes, uint32_t* n_leaf_slots) {
@@ -766,21 +925,41 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
     return PT_OK;
 }
 
-int pt_render_host(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* out_linear, uint8_t* out_rgba) {
-    if (!c || !cam || !prm || !out_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_host: null argument");
-    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
-    const size_t np = (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
-    if (np == 0) return pt_render_device(c, cam, prm, nullptr, nullptr);   // validates, renders nothing
+}  // extern "C"
+
+namespace {
+
+// render_impl into the context's device staging, then over PCIe into the caller's host buffers (blocking)
+int render_to_host(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, const FilmState& fs, const ListRender* list,
+                   size_t np, float* out_linear, uint8_t* out_rgba) {
+    if (np == 0) return render_impl(c, cam, prm, fs, list, nullptr, nullptr);   // validates, renders nothing
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = c->host_lin.ensure(np * 3))) return rc;
     if (out_rgba && (rc = c->host_rgba.ensure(np * 4))) return rc;
-    rc = pt_render_device(c, cam, prm, c->host_lin.p, out_rgba ? c->host_rgba.p : nullptr);
+    rc = render_impl(c, cam, prm, fs, list, c->host_lin.p, out_rgba ? c->host_rgba.p : nullptr);
     if (!rc) rc = pt_sync(c);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out_linear, c->host_lin.p, np * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, c->host_rgba.p, np * 4, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+size_t tile_pixels(const PtCamera* cam, const PtRenderParams* prm) {
+    return (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, prm->band_count ? prm->band_count : 1) * cam->width;
+}
+
+// the contexts pt_render() keeps between calls (one per device it has been asked to use)
+std::mutex g_render_mu;
+std::vector<PtContext*> g_render_ctx;
+bool g_atexit_registered = false;
+
+}  // namespace
+
+extern "C" {
+
+int pt_render_host(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* out_linear, uint8_t* out_rgba) {
+    if (!c || !cam || !prm || !out_linear) return fail(PT_ERR_INVALID_ARG, "pt_render_host: null argument");
+    return render_to_host(c, cam, prm, FilmState{}, nullptr, tile_pixels(cam, prm), out_linear, out_rgba);
 }
 
 // The progressive preview of the reference (main.rs:79-90 redraws World.data every 16 ms while
@@ -792,34 +971,121 @@ int pt_render_progressive(PtContext* c, const PtCamera* cam, const PtRenderParam
         return fail(PT_ERR_INVALID_ARG, "pt_render_progressive: null argument");
     if (prm->spp == 0) return fail(PT_ERR_INVALID_ARG, "spp must be > 0");
     if (spp_step == 0) spp_step = prm->spp;
-    const uint32_t band_count = prm->band_count ? prm->band_count : 1;
-    const size_t np = (size_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
+    const size_t np = tile_pixels(cam, prm);
     int rc = PT_OK;
     for (uint32_t done = 0; done < prm->spp && rc == PT_OK;) {
         const uint32_t n = std::min(spp_step, prm->spp - done);
         PtRenderParams p = *prm;
         p.spp = n;
         p.spp_offset = prm->spp_offset + done;
-        c->prog_load = done > 0;
-        c->prog_store = done + n < prm->spp;
-        c->prog_div = done + n;
-        rc = pt_render_host(c, cam, &p, out_linear, out_rgba);
-        c->prog_load = c->prog_store = false;
-        c->prog_div = 0;
+        FilmState fs;                   // the f64 sums of the film stay on the device between increments
+        fs.load = done > 0;
+        fs.store = done + n < prm->spp;
+        fs.div = done + n;
+        rc = render_to_host(c, cam, &p, fs, nullptr, np, out_linear, out_rgba);
         done += n;
         if (rc == PT_OK && np != 0 && fn && fn(user, done, prm->spp, out_rgba, out_linear) != 0) break;   // caller asked to stop
     }
     return rc;
 }
 
+int pt_render_pixels(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, const uint32_t* xy, uint32_t n,
+                     float* out_linear, uint8_t* out_rgba, float* out_samples) {
+    if (!c || !cam || !prm || (n && (!xy || !out_linear))) return fail(PT_ERR_INVALID_ARG, "pt_render_pixels: null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (xy[2 * i] >= cam->width || xy[2 * i + 1] >= cam->height)
+            return fail(PT_ERR_INVALID_ARG, "pixel %u = (%u, %u) is outside the %ux%u image", i, xy[2 * i], xy[2 * i + 1], cam->width, cam->height);
+    ListRender lr;
+    if (n) {
+        HIP_TRY(hipSetDevice(c->device));
+        int rc = c->pixel_list.ensure(n);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));            // an earlier list may still be in use
+        HIP_TRY(hipMemcpy(c->pixel_list.p, xy, (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
+        lr.d_pixels = c->pixel_list.p;
+    }
+    lr.n = n;
+    if (out_samples && n) {
+        const uint64_t cap = std::min<uint64_t>(prm->max_paths_in_flight ? prm->max_paths_in_flight : kDefaultMaxPaths, 1ull << 30);
+        if ((uint64_t)n * prm->spp > cap || prm->spp > 65535u)
+            return fail(PT_ERR_UNSUPPORTED, "pt_render_pixels: out_samples needs n * spp = %llu paths in one sample batch (limit %llu, spp < 65536)",
+                        (unsigned long long)n * prm->spp, (unsigned long long)cap);
+    }
+    int rc = render_to_host(c, cam, prm, FilmState{}, &lr, n, out_linear, out_rgba);
+    if (rc || !out_samples || !n) return rc;
+    // the batch's per-path radiance buffer, index = sample * n + pixel  ->  [pixel][sample][rgb]
+    std::vector<float4> ls((size_t)n * prm->spp);
+    HIP_TRY(hipMemcpy(ls.data(), c->lsamp.p, ls.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t sidx = 0; sidx < prm->spp; ++sidx) {
+            const float4 v = ls[(size_t)sidx * n + i];
+            float* o = out_samples + ((size_t)i * prm->spp + sidx) * 3;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z;
+        }
+    return PT_OK;
+}
+
+int pt_ray_color(PtContext* c, const PtRenderParams* prm, const double* rays, const uint32_t* xy, uint32_t n, float* out_rgb) {
+    if (!c || !prm || (n && (!rays || !xy || !out_rgb))) return fail(PT_ERR_INVALID_ARG, "pt_ray_color: null argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // the paths in queue form (pt_kernels.h): depth 0, throughput 1, no radiance yet, film slot = ray index
+    std::vector<float4> plane[4];
+    for (auto& pl : plane) pl.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float o[3] = {(float)rays[6 * (size_t)i], (float)rays[6 * (size_t)i + 1], (float)rays[6 * (size_t)i + 2]};
+        float d[3] = {(float)rays[6 * (size_t)i + 3], (float)rays[6 * (size_t)i + 4], (float)rays[6 * (size_t)i + 5]};
+        // Ray::new normalises (camera.rs:10-16): Vector3::normalize in the f32 arithmetic of the device's exact mode
+        const float len = std::sqrt(std::fmaf(d[2], d[2], std::fmaf(d[1], d[1], d[0] * d[0])));
+        if (len > 0.0f) { const float inv = 1.0f / len; d[0] *= inv; d[1] *= inv; d[2] *= inv; }
+        const uint32_t slot = i, sd = 0u;     // (tile_row << 16 | x) of a 65536-wide film; (s_local << 16 | depth)
+        float fslot, fsd;
+        std::memcpy(&fslot, &slot, 4); std::memcpy(&fsd, &sd, 4);
+        plane[0][i] = make_float4(o[0], o[1], o[2], d[0]);
+        plane[1][i] = make_float4(d[1], d[2], 1.0f, 1.0f);
+        plane[2][i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        plane[3][i] = make_float4(0.0f, 1.0f, fslot, fsd);      // pdf_prev 0, eta_ratio 1 (camera.rs:14)
+    }
+    int rc;
+    if ((rc = c->pixel_list.ensure(n))) return rc;
+    for (int k = 0; k < 4; ++k) if ((rc = c->inject[k].ensure(n))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->pixel_list.p, xy, (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
+    ListRender lr;
+    lr.d_pixels = c->pixel_list.p; lr.n = n;
+    for (int k = 0; k < 4; ++k) {
+        HIP_TRY(hipMemcpy(c->inject[k].p, plane[k].data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
+        lr.inject[k] = c->inject[k].p;
+    }
+    PtCamera cam{};                     // no camera rays are generated
+    cam.width = cam.height = 2;
+    return render_to_host(c, &cam, prm, FilmState{}, &lr, n, out_rgb, nullptr);
+}
+
+void pt_shutdown(void) {
+    pt_internal_multi_shutdown();
+    std::lock_guard<std::mutex> lk(g_render_mu);
+    for (PtContext* c : g_render_ctx) pt_context_destroy(c);
+    g_render_ctx.clear();
+}
+
 int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRenderParams* prm, float* out_linear,
               uint8_t* out_rgba) {
     if (!cam || !prm || !out_linear) return fail(PT_ERR_INVALID_ARG, "pt_render: null argument");
-    static std::mutex mu;
-    static PtContext* ctx = nullptr;
-    std::lock_guard<std::mutex> lk(mu);
+    if (prm->n_devices > 1) {
+        std::vector<int> dev(prm->n_devices);
+        for (uint32_t i = 0; i < prm->n_devices; ++i) dev[i] = (int)i;
+        return pt_render_multi(dev.data(), prm->n_devices, cam, objs, n, prm, out_linear, out_rgba);
+    }
+    std::lock_guard<std::mutex> lk(g_render_mu);
     int rc;
-    if (!ctx && (rc = pt_context_create(0, &ctx))) return rc;
+    if (g_render_ctx.empty()) {
+        PtContext* ctx = nullptr;
+        if ((rc = pt_context_create(0, &ctx))) return rc;
+        g_render_ctx.push_back(ctx);
+        if (!g_atexit_registered) { std::atexit(pt_shutdown); g_atexit_registered = true; }
+    }
+    PtContext* ctx = g_render_ctx[0];
     if ((rc = pt_scene_upload(ctx, objs, n))) return rc;
     return pt_render_host(ctx, cam, prm, out_linear, out_rgba);
 }

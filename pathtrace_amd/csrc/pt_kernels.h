@@ -82,6 +82,14 @@ struct BounceArgs {
     SceneView sc;
     CameraF cam;
     uint32_t n_first;         // paths of the batch
+    // continuation launches may take their path count from device memory instead (the counter the previous launch's
+    // waves added their leftovers to): the host then never waits for it.  seg_cap is derived on the device in that case.
+    const uint32_t* n_first_dev;
+    // pixel-list renders (pt_render_pixels / pt_ray_color): film slot i = (tile_row << 16) | x of the path state,
+    // RNG key and camera pixel = pixels[i] = (x, y) of the image.  film_w = row pitch of the film-slot arithmetic
+    // (camera width, or 65536 for a list).
+    const uint2* pixels;
+    uint32_t film_w;
     uint32_t np;              // pixels of the tile
     uint32_t s_base;          // sample index of s_local = 0 (spp_offset + batch start)
     uint32_t min_depth, max_depth;
@@ -124,11 +132,31 @@ struct ResolveArgs {
 };
 void launch_resolve(const ResolveArgs& a, hipStream_t st);
 
+// Multi-GPU film exchange (pt_multi.cpp): tile -> 16 B per pixel (linear RGB + RGBA8) before the gather, gathered
+// padded tiles -> frame in image order after it.
+void launch_film_pack(const float* lin, const uint8_t* rgba, uint32_t np, void* packed, hipStream_t st);
+void launch_film_unpack(const void* recv, uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_dev, uint32_t max_rows, float* lin,
+                        uint8_t* rgba, hipStream_t st);
+
 // World::hit_scene on arbitrary rays (debug/parity entry).
-// scratch: accel = 1 only, 3*n float4 of device memory
+// scratch: accel = 1 only, 3*n float4 of device memory.  out_rec: optional, 8 floats per ray (t, point3, normal3, front_face).
 void launch_debug_hit_exact(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min, float t_max,
-                            float4* scratch, int32_t* out_id, float* out_t, hipStream_t st);
+                            float4* scratch, int32_t* out_id, float* out_t, float* out_rec, hipStream_t st);
 void launch_debug_hit_fast(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min, float t_max,
-                           float4* scratch, int32_t* out_id, float* out_t, hipStream_t st);
+                           float4* scratch, int32_t* out_id, float* out_t, float* out_rec, hipStream_t st);
+
+// The per-vertex functions on arbitrary inputs (debug/parity entries; layouts at k_debug_fn in pt_kernels.hip).
+enum { kFnBsdfEval = 0, kFnBsdfSample = 1, kFnShapeSample = 2, kFnLightPoint = 3, kFnCameraRay = 4 };
+struct DebugFnArgs {
+    SceneView sc;
+    CameraF cam;              // kFnCameraRay only
+    uint32_t op, obj, n;
+    uint32_t in_stride, out_stride;   // floats per item
+    const float* in;
+    const uint32_t* words;    // 4 raw words per item, or null
+    float* out;
+};
+void launch_debug_fn_exact(const DebugFnArgs& a, hipStream_t st);
+void launch_debug_fn_fast(const DebugFnArgs& a, hipStream_t st);
 
 }  // namespace ptk

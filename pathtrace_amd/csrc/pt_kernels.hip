@@ -322,9 +322,10 @@ PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, ui
 // (id, t) = closest hit of the path ray, id < 0: miss.  Credits an emitter hit into p.L and samples the light point.
 // DIFFUSE: the scene has Lambertian and emissive materials only (decided at pt_scene_upload); the GGX and
 // OrenNayar code is then compiled out of the kernel (same results; smaller code, no spills at 6 waves/SIMD: C2 +2 %).
+// (kx, py) = the pixel's RNG key (main.rs:51); it is the path's film position except in pixel-list renders.
 template <bool MIS, bool DIFFUSE>
-PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, float t, uint32_t sample, uint32_t py,
-                         Vertex& v) {
+PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, float t, uint32_t sample, uint32_t kx,
+                         uint32_t py, Vertex& v) {
     v.alive = active && id >= 0;
     v.obj = id >= 0 ? id : 0; v.light_obj = 0;
     v.hit.point = p.o; v.hit.normal = p.d; v.hit.t = 0.0f; v.hit.front_face = false;
@@ -356,13 +357,13 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
     v.w_bsdf1 = v.w_bsdf2 = v.w_lobe = v.w_rr = 0u;
     if (v.alive) {
         uint32_t ds[4];
-        philox4x32_10(sample, p.depth, BLK_SURFACE, 0u, p.px, py, ds);
+        philox4x32_10(sample, p.depth, BLK_SURFACE, 0u, kx, py, ds);
         v.w_bsdf1 = ds[2]; v.w_bsdf2 = ds[3];
         if (MIS && sc.n_lights > 0u) {
             uint32_t w_index = 0u;                                                // umulhi(u, 1) = 0: one light needs no draw
             if (sc.n_lights > 1u) {
                 uint32_t dc[4];
-                philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, p.px, py, dc);
+                philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, kx, py, dc);
                 w_index = dc[0]; v.w_lobe = dc[1]; v.w_rr = dc[2];
             }
             f3 lp;
@@ -381,8 +382,8 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
 // being carried across the visibility scan -- two broadcast LDS reads instead of ~6 live registers, which is what
 // keeps the kernel at 80 VGPRs without spills.
 template <bool MIS, bool DIFFUSE, bool REMAT>
-PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool visible, uint32_t sample, uint32_t py,
-                       uint32_t min_depth, uint32_t max_depth) {
+PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool visible, uint32_t sample, uint32_t kx,
+                       uint32_t py, uint32_t min_depth, uint32_t max_depth) {
     const uint32_t n_lights = sc.n_lights;
     Vertex v = vin;
     if (REMAT) {
@@ -408,7 +409,7 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
         uint32_t w_lobe = v.w_lobe, w_rr = v.w_rr;
         if (!(MIS && n_lights > 1u) && (v.m.tag == MAT_MIRROR || p.depth >= min_depth)) {
             uint32_t dc[4];
-            philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, p.px, py, dc);
+            philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, kx, py, dc);
             w_lobe = dc[1]; w_rr = dc[2];
         }
         float eta_mat = v.m.tag == MAT_MIRROR ? v.m.ior : 1.0f;               // get_eta, material.rs:50 / mirror.rs:317
@@ -473,7 +474,22 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
 #ifndef PT_BOUNCE_WAVES_TILED
 #define PT_BOUNCE_WAVES_TILED 5
 #endif
-template <int MODE, bool MIS, bool OVF, bool DIFFUSE>   // OVF: continuation launch, pass 0 reads the overflow queue
+// film position of a path -> its pixel: the RNG key (x, y) and camera pixel.  LIST: looked up in the pixel list.
+template <bool LIST>
+PT_DEV void pixel_key(const BounceArgs& a, const PathState& p, uint32_t& kx, uint32_t& py) {
+    if (LIST) { const uint2 k = a.pixels[(p.yl << 16) | p.px]; kx = k.x; py = k.y; }
+    else { kx = p.px; py = image_row(a.tile, p.yl); }
+}
+// a continuation launch whose path count is only known on the device: count, chunks and segment size from there
+template <bool OVF>
+PT_DEV void launch_shape(const BounceArgs& a, uint32_t nw, uint32_t& n_first, uint32_t& seg_cap) {
+    n_first = a.n_first; seg_cap = a.seg_cap;
+    if (OVF && a.n_first_dev) {
+        n_first = __builtin_amdgcn_readfirstlane(*a.n_first_dev);
+        seg_cap = ((((n_first + 63u) >> 6) + nw - 1u) / nw) * 64u;
+    }
+}
+template <int MODE, bool MIS, bool OVF, bool DIFFUSE, bool LIST>   // OVF: continuation launch, pass 0 reads the overflow queue
 __global__ void __launch_bounds__(kBlock, MODE == kModeLds ? PT_BOUNCE_WAVES_LDS : PT_BOUNCE_WAVES_TILED)
 k_paths(BounceArgs a) {
     // SMALL = "the waves of a workgroup are independent" (no barrier inside the scan): wave-private queue
@@ -491,9 +507,11 @@ k_paths(BounceArgs a) {
     // goes to wave c % 4 and only the last chunk of a pass is partial (every pass costs a full scan of the
     // whole scene per wave, however few lanes are alive).
     const uint32_t wib = threadIdx.x >> 6;                       // wave in block
-    const uint32_t seg_base = SMALL ? wave * a.seg_cap : blockIdx.x * (kBlock / 64) * a.seg_cap;
-    const uint32_t n_chunks = (a.n_first + 63u) >> 6;              // pass 0: 64-path chunks of the batch
-    const uint32_t W = a.cam.width;
+    uint32_t n_first, seg_cap;
+    launch_shape<OVF>(a, nw, n_first, seg_cap);
+    const uint32_t seg_base = SMALL ? wave * seg_cap : blockIdx.x * (kBlock / 64) * seg_cap;
+    const uint32_t n_chunks = (n_first + 63u) >> 6;                // pass 0: 64-path chunks of the batch
+    const uint32_t W = a.film_w;
     uint32_t n_in = 0;                     // wave-uniform: queued paths of this wave's segment
     uint32_t wave_shadow = 0, wave_vertices = 0;
     uint32_t wave_depth = 0;               // wave-uniform: deepest vertex this wave has processed
@@ -517,7 +535,7 @@ k_paths(BounceArgs a) {
             p = parked_state();
             const uint32_t chunk = it * nw + wave;
             const uint32_t pid = chunk * 64u + lane;
-            active = chunk < n_chunks && pid < a.n_first;
+            active = chunk < n_chunks && pid < n_first;
             if (active) {
                 if (from_overflow) {
                     // continuation launch: the paths are the leftovers an earlier launch exported
@@ -537,10 +555,11 @@ k_paths(BounceArgs a) {
             p = unpack_state(a.q.q[0][s0], a.q.q[1][s0], a.q.q[2][s0], a.q.q[3][s0]);
             if (!active) { p.o = parked_origin(); p.d = parked_dir(); }
         }
-        const uint32_t py = image_row(a.tile, p.yl);     // key of the path's RNG stream = (x, y), main.rs:51
+        uint32_t kx, py;                                  // key of the path's RNG stream = (x, y), main.rs:51
+        pixel_key<LIST>(a, p, kx, py);
         const uint32_t sample = a.s_base + p.s_local;
 
-        if (first && !from_overflow && active) camera_ray(a.cam, sample, p.px, py, p.o, p.d);
+        if (first && !from_overflow && active) camera_ray(a.cam, sample, kx, py, p.o, p.d);
 
         wave_vertices += (uint32_t)__popcll(__ballot(active));
         // deepest vertex: in a level-0 launch every path of pass p is at depth p; only a continuation launch
@@ -557,7 +576,7 @@ k_paths(BounceArgs a) {
         int id; float t;
         scan_closest<MODE>(sc, p.o, p.d, a.t_min, kInf, id, t);
         Vertex v;
-        vertex_begin<MIS, DIFFUSE>(sc, p, active, id, t, sample, py, v);
+        vertex_begin<MIS, DIFFUSE>(sc, p, active, id, t, sample, kx, py, v);
 
         // ---- scan #2: visibility (rendering.rs:62-65); skipped when no lane needs it
         bool visible = false;
@@ -574,7 +593,7 @@ k_paths(BounceArgs a) {
                 wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
         }
-        const bool alive = vertex_end<MIS, DIFFUSE, SMALL>(sc, p, v, visible, sample, py, a.min_depth, a.max_depth);
+        const bool alive = vertex_end<MIS, DIFFUSE, SMALL>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
 
         // ---- retire, or compact in place into the wave's own segment
         if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
@@ -782,16 +801,18 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
 #ifndef PT_BVH_WAVES
 #define PT_BVH_WAVES 5      // measured on C4: 4 -> 74.0 ms, 5 -> 70.2 ms, 6 (spills) -> 72.8 ms
 #endif
-template <bool MIS, bool OVF, bool DIFFUSE>
+template <bool MIS, bool OVF, bool DIFFUSE, bool LIST>
 __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a) {
     extern __shared__ float4 lds[];
     const SceneRef sc = stage_scene<kModeBvh>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (kBlock / 64);
-    const uint32_t seg_base = wave * a.seg_cap;
-    const uint32_t n_chunks = (a.n_first + 63u) >> 6;
-    const uint32_t W = a.cam.width;
+    uint32_t n_first, seg_cap;
+    launch_shape<OVF>(a, nw, n_first, seg_cap);
+    const uint32_t seg_base = wave * seg_cap;
+    const uint32_t n_chunks = (n_first + 63u) >> 6;
+    const uint32_t W = a.film_w;
     const Queue q = {{a.q.q[0] + seg_base, a.q.q[1] + seg_base, a.q.q[2] + seg_base, a.q.q[3] + seg_base}};
     float4* const aux = a.aux + seg_base;
     float4* const sr0 = a.sray0 + seg_base;
@@ -803,7 +824,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
     for (uint32_t it = 0, n_iter = (n_chunks + nw - 1u) / nw; it < n_iter; ++it) {
         const uint32_t chunk = it * nw + wave;
         const uint32_t pid = chunk * 64u + lane;
-        const bool active = chunk < n_chunks && pid < a.n_first;
+        const bool active = chunk < n_chunks && pid < n_first;
         if (active) {
             PathState p = parked_state();
             if (OVF) {
@@ -813,7 +834,9 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 const uint32_t pix = pid - p.s_local * a.np;
                 p.yl = pix / W;
                 p.px = pix - p.yl * W;
-                camera_ray(a.cam, a.s_base + p.s_local, p.px, image_row(a.tile, p.yl), p.o, p.d);
+                uint32_t kx, py;
+                pixel_key<LIST>(a, p, kx, py);
+                camera_ray(a.cam, a.s_base + p.s_local, kx, py, p.o, p.d);
             }
             store_state(q, it * 64u + lane, p);     // dense: only the last chunk of the batch can be partial
         }
@@ -835,7 +858,9 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
                 if (active) { p = unpack_state(q.q[0][s], q.q[1][s], make_float4(0.f, 0.f, 0.f, 0.f), q.q[3][s]); h = aux[s]; }
                 Vertex v;
-                vertex_begin<true, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, a.s_base + p.s_local, image_row(a.tile, p.yl), v);
+                uint32_t kx, py;
+                pixel_key<LIST>(a, p, kx, py);
+                vertex_begin<true, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, a.s_base + p.s_local, kx, py, v);
                 if (active) {
                     sr0[s] = make_float4(v.hit.point.x, v.hit.point.y, v.hit.point.z, v.light_dir.x);
                     sr1[s] = make_float4(v.light_dir.y, v.light_dir.z, v.distance - a.t_min, v.need_shadow ? 1.0f : 0.0f);
@@ -855,7 +880,8 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             PathState p = parked_state();
             float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
             if (active) { p = unpack_state(q.q[0][s], q.q[1][s], q.q[2][s], q.q[3][s]); h = aux[s]; }
-            const uint32_t py = image_row(a.tile, p.yl);
+            uint32_t kx, py;
+            pixel_key<LIST>(a, p, kx, py);
             const uint32_t sample = a.s_base + p.s_local;
             wave_vertices += (uint32_t)__popcll(__ballot(active));
             if (!OVF) {
@@ -866,9 +892,9 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 wave_depth = __builtin_amdgcn_readfirstlane(m);
             }
             Vertex v;
-            vertex_begin<MIS, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, sample, py, v);
+            vertex_begin<MIS, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, sample, kx, py, v);
             const bool visible = MIS && v.need_shadow && h.z == 0.0f;
-            const bool alive = vertex_end<MIS, DIFFUSE, false>(sc, p, v, visible, sample, py, a.min_depth, a.max_depth);
+            const bool alive = vertex_end<MIS, DIFFUSE, false>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
             if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
             const unsigned long long mask = __ballot(alive);
             if (alive) store_state(q, out_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
@@ -903,25 +929,25 @@ static size_t scene_lds_bytes(const SceneView& sc, int mode) {
     if (mode == kModeBvh) return (size_t)kBvhStack * kBlock * sizeof(uint32_t);
     return (mode == kModeLds ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
 }
-template <int MODE, bool DIFFUSE>
+template <int MODE, bool DIFFUSE, bool LIST>
 static void launch_paths_mode(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
     const bool mis = a.integrator == 0;
     const bool ovf = a.src_mode != 0u;     // continuation launch
     const dim3 g(grid), b(kBlock);
-    if (mis && !ovf) hipLaunchKernelGGL((k_paths<MODE, true, false, DIFFUSE>), g, b, lds, st, a);
-    else if (mis) hipLaunchKernelGGL((k_paths<MODE, true, true, DIFFUSE>), g, b, lds, st, a);
-    else if (!ovf) hipLaunchKernelGGL((k_paths<MODE, false, false, DIFFUSE>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_paths<MODE, false, true, DIFFUSE>), g, b, lds, st, a);
+    if (mis && !ovf) hipLaunchKernelGGL((k_paths<MODE, true, false, DIFFUSE, LIST>), g, b, lds, st, a);
+    else if (mis) hipLaunchKernelGGL((k_paths<MODE, true, true, DIFFUSE, LIST>), g, b, lds, st, a);
+    else if (!ovf) hipLaunchKernelGGL((k_paths<MODE, false, false, DIFFUSE, LIST>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_paths<MODE, false, true, DIFFUSE, LIST>), g, b, lds, st, a);
 }
-template <bool DIFFUSE>
+template <bool DIFFUSE, bool LIST>
 static void launch_paths_bvh(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
     const bool mis = a.integrator == 0;
     const bool ovf = a.src_mode != 0u;
     const dim3 g(grid), b(kBlock);
-    if (mis && !ovf) hipLaunchKernelGGL((k_paths_bvh<true, false, DIFFUSE>), g, b, lds, st, a);
-    else if (mis) hipLaunchKernelGGL((k_paths_bvh<true, true, DIFFUSE>), g, b, lds, st, a);
-    else if (!ovf) hipLaunchKernelGGL((k_paths_bvh<false, false, DIFFUSE>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((k_paths_bvh<false, true, DIFFUSE>), g, b, lds, st, a);
+    if (mis && !ovf) hipLaunchKernelGGL((k_paths_bvh<true, false, DIFFUSE, LIST>), g, b, lds, st, a);
+    else if (mis) hipLaunchKernelGGL((k_paths_bvh<true, true, DIFFUSE, LIST>), g, b, lds, st, a);
+    else if (!ovf) hipLaunchKernelGGL((k_paths_bvh<false, false, DIFFUSE, LIST>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_paths_bvh<false, true, DIFFUSE, LIST>), g, b, lds, st, a);
 }
 
 }  // namespace PTK_IMPL
@@ -931,9 +957,15 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
     const int mode = scene_mode(a.sc, a.accel);
     const size_t lds = scene_lds_bytes(a.sc, mode);
     const bool diffuse = a.sc.diffuse_only != 0u;
-    if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true>(a, grid, lds, st); else launch_paths_mode<kModeLds, false>(a, grid, lds, st); }
-    else if (mode == kModeTiled) launch_paths_mode<kModeTiled, false>(a, grid, lds, st);   // scan-dominated: the variant buys nothing (measured)
-    else { if (diffuse) launch_paths_bvh<true>(a, grid, lds, st); else launch_paths_bvh<false>(a, grid, lds, st); }
+    if (a.pixels) {      // pixel-list renders: the generic kernels only (debug / replay entries, not the throughput path)
+        if (mode == kModeLds) launch_paths_mode<kModeLds, false, true>(a, grid, lds, st);
+        else if (mode == kModeTiled) launch_paths_mode<kModeTiled, false, true>(a, grid, lds, st);
+        else launch_paths_bvh<false, true>(a, grid, lds, st);
+        return;
+    }
+    if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }
+    else if (mode == kModeTiled) launch_paths_mode<kModeTiled, false, false>(a, grid, lds, st);   // scan-dominated: the variant buys nothing (measured)
+    else { if (diffuse) launch_paths_bvh<true, false>(a, grid, lds, st); else launch_paths_bvh<false, false>(a, grid, lds, st); }
 }
 }  // namespace ptk
 namespace PTK_IMPL {
@@ -968,18 +1000,62 @@ __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
 }
 }  // namespace PTK_IMPL
 #if !PT_MATH_EXACT
-namespace ptk {   // the film resolve has no division or sqrt in f32: one copy serves both modes
+namespace PTK_IMPL {
+// ------------------------------------------------------------------ multi-GPU film exchange (pt_multi.cpp)
+// A device's tile -> one 16-byte record per pixel (12 B linear RGB + 4 B RGBA8), so that both film planes travel in
+// ONE gather; rows beyond the tile (tiles are padded to the largest one) are left untouched.
+__global__ void __launch_bounds__(kBlock) k_film_pack(const float* __restrict__ lin, const uint8_t* __restrict__ rgba,
+                                                      uint32_t np, uint4* __restrict__ packed) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= np) return;
+    uint4 v;
+    v.x = __float_as_uint(lin[3 * (size_t)p]); v.y = __float_as_uint(lin[3 * (size_t)p + 1]); v.z = __float_as_uint(lin[3 * (size_t)p + 2]);
+    v.w = rgba ? *reinterpret_cast<const uint32_t*>(rgba + 4 * (size_t)p) : 0u;
+    packed[p] = v;
+}
+// The gathered tiles (device g's padded tile at recv + g * max_rows * W) -> the frame in image order.  Image row y lies
+// in band y / band_rows, which device (band % n_dev) rendered as its tile row (band / n_dev) * band_rows + y % band_rows.
+__global__ void __launch_bounds__(kBlock) k_film_unpack(const uint4* __restrict__ recv, uint32_t W, uint32_t H, uint32_t band_rows,
+                                                        uint32_t n_dev, uint32_t max_rows, float* __restrict__ lin,
+                                                        uint8_t* __restrict__ rgba) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= W * H) return;
+    const uint32_t y = p / W, x = p - y * W;
+    const uint32_t band = y / band_rows, g = band % n_dev;
+    const uint32_t k = (band / n_dev) * band_rows + (y - band * band_rows);
+    const uint4 v = recv[((size_t)g * max_rows + k) * W + x];
+    lin[3 * (size_t)p] = __uint_as_float(v.x); lin[3 * (size_t)p + 1] = __uint_as_float(v.y); lin[3 * (size_t)p + 2] = __uint_as_float(v.z);
+    if (rgba) *reinterpret_cast<uint32_t*>(rgba + 4 * (size_t)p) = v.w;
+}
+}  // namespace PTK_IMPL
+namespace ptk {   // the film kernels have no division or sqrt in f32: one copy serves both modes
 void launch_resolve(const ResolveArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(PTK_IMPL::k_resolve, dim3((a.np + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
+}
+void launch_film_pack(const float* lin, const uint8_t* rgba, uint32_t np, void* packed, hipStream_t st) {
+    if (np) hipLaunchKernelGGL(PTK_IMPL::k_film_pack, dim3((np + kBlock - 1) / kBlock), dim3(kBlock), 0, st, lin, rgba, np, (uint4*)packed);
+}
+void launch_film_unpack(const void* recv, uint32_t W, uint32_t H, uint32_t band_rows, uint32_t n_dev, uint32_t max_rows, float* lin,
+                        uint8_t* rgba, hipStream_t st) {
+    if (W * H) hipLaunchKernelGGL(PTK_IMPL::k_film_unpack, dim3((W * H + kBlock - 1) / kBlock), dim3(kBlock), 0, st, (const uint4*)recv, W, H,
+                                  band_rows, n_dev, max_rows, lin, rgba);
 }
 }  // namespace ptk
 #endif
 namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ debug: hit_scene on arbitrary rays
+// HitRecord of the winning object (shape.rs:84-88 / 194-197 + base.rs:19-33): rec[8] = (t, point3, normal3, front_face)
+PT_DEV void store_hit_record(const SceneRef& sc, int id, f3 o, f3 d, float t, float* rec) {
+    Hit h;
+    h.t = 0.0f; h.point = mk(0.f, 0.f, 0.f); h.normal = mk(0.f, 0.f, 0.f); h.front_face = false;
+    if (id >= 0) h = finish_hit(sc.shape, id, load_mat(sc.mat, id).shape_tag, o, d, t);
+    rec[0] = h.t; rec[1] = h.point.x; rec[2] = h.point.y; rec[3] = h.point.z;
+    rec[4] = h.normal.x; rec[5] = h.normal.y; rec[6] = h.normal.z; rec[7] = h.front_face ? 1.0f : 0.0f;
+}
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float* __restrict__ rays6, uint32_t n,
-                                                      float t_min, float t_max, int32_t* out_id, float* out_t) {
+                                                      float t_min, float t_max, int32_t* out_id, float* out_t, float* out_rec) {
     extern __shared__ float4 lds[];
     const SceneRef sc = stage_scene<MODE>(scv, lds);
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
@@ -993,13 +1069,14 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float
         int id; float t;
         scan_closest<MODE>(sc, o, d, t_min, t_max, id, t);
         if (active) { out_id[i] = id; out_t[i] = id >= 0 ? t : 0.0f; }
+        if (active && out_rec) store_hit_record(sc, id, o, d, t, out_rec + 8 * (size_t)i);
     }
 }
 // the same through the BVH: every wave packs a contiguous slice of the rays into segment form and runs
 // traverse_segment (the routine of k_paths_bvh) over it
 __global__ void __launch_bounds__(kBlock) k_debug_hit_bvh(SceneView scv, const float* __restrict__ rays6, uint32_t n,
                                                           float t_min, float t_max, float4* p0, float4* p1, float4* res,
-                                                          int32_t* out_id, float* out_t) {
+                                                          int32_t* out_id, float* out_t, float* out_rec) {
     extern __shared__ float4 lds[];
     const SceneRef sc = stage_scene<kModeBvh>(scv, lds);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1024,25 +1101,88 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit_bvh(SceneView scv, const f
         const int id = __float_as_int(r.x);
         out_id[base + k] = id;
         out_t[base + k] = id >= 0 ? r.y : 0.0f;
+        if (out_rec) {
+            const float4 q0 = p0[base + k], q1 = p1[base + k];
+            store_hit_record(sc, id, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), r.y, out_rec + 8 * (size_t)(base + k));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ debug: the per-vertex functions on arbitrary inputs
+// One thread per item; the SAME device functions the path kernels inline (pt_device.h, sample_light_point, camera_ray).
+//   kFnBsdfEval    Material::bsdf_pdf (material.rs:86-91,139-148,221-265; mirror.rs:179-198)
+//                  in[10] = dir_in3, wo3, normal3, eta -> out[4] = f3, pdf
+//   kFnBsdfSample  Material::bsdf_pdf_sample (material.rs:29-40, mirror.rs:200-305)
+//                  in[7] = dir_in3, normal3, eta; words[4] = r1, r2, lobe u, - -> out[8] = wo3, f3, pdf, cos
+//   kFnShapeSample Shape::sample_surface_from_point (shape.rs:91-145, 200-242)
+//                  in[9] = from3, target3, r1, r2, with_target -> out[8] = point3, pdf_omega, light_dir3, distance
+//                  (direction and distance as rendering.rs:58-60 forms them)
+//   kFnLightPoint  World::sample_light_point (world.rs:251-267)
+//                  in[3] = from3; words[4] = index word, r1 word, r2 word, - -> out[8] = point3, emission3, pdf, light object
+//   kFnCameraRay   Camera::get_ray_with_offset with the sample's jitter draws (camera.rs:139-147, world.rs:299)
+//                  words[4] = x, y (top-down film row), sample, - -> out[8] = origin3, direction3, ox, oy
+__global__ void __launch_bounds__(kBlock) k_debug_fn(DebugFnArgs a) {
+    extern __shared__ float4 lds[];
+    const SceneRef sc = stage_scene<kModeBvh>(a.sc, lds);      // records from global memory, nothing staged
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const float* in = a.in + (size_t)i * a.in_stride;
+    const uint32_t* w = a.words ? a.words + 4 * (size_t)i : nullptr;
+    float* out = a.out + (size_t)i * a.out_stride;
+    if (a.op == kFnBsdfEval) {
+        const Mat m = load_mat(sc.mat, (int)a.obj);
+        f3 f; float pdf;
+        bsdf_pdf(m, mk(in[0], in[1], in[2]), in[9], mk(in[3], in[4], in[5]), mk(in[6], in[7], in[8]), f, pdf);
+        out[0] = f.x; out[1] = f.y; out[2] = f.z; out[3] = pdf;
+    } else if (a.op == kFnBsdfSample) {
+        const Mat m = load_mat(sc.mat, (int)a.obj);
+        f3 wo, f; float pdf, c;
+        bsdf_pdf_sample(m, mk(in[0], in[1], in[2]), in[6], mk(in[3], in[4], in[5]), w[0], w[1], w[2], wo, f, pdf, c);
+        out[0] = wo.x; out[1] = wo.y; out[2] = wo.z; out[3] = f.x; out[4] = f.y; out[5] = f.z; out[6] = pdf; out[7] = c;
+    } else if (a.op == kFnShapeSample) {
+        const Mat m = load_mat(sc.mat, (int)a.obj);
+        const f3 from = mk(in[0], in[1], in[2]);
+        f3 point; float pdf;
+        shape_sample(sc.shape, (int)a.obj, m.shape_tag, from, in[8] != 0.0f, mk(in[3], in[4], in[5]), in[6], in[7], point, pdf);
+        const f3 to_light = point - from;
+        const f3 dir = normalize(to_light);
+        out[0] = point.x; out[1] = point.y; out[2] = point.z; out[3] = pdf;
+        out[4] = dir.x; out[5] = dir.y; out[6] = dir.z; out[7] = length(to_light);
+    } else if (a.op == kFnLightPoint) {
+        f3 point = mk(0.f, 0.f, 0.f), le = point; float pdf = 0.0f; int lobj = -1;
+        if (sc.n_lights > 0u) sample_light_point<false>(sc, mk(in[0], in[1], in[2]), w[0], w[1], w[2], point, lobj, le, pdf);
+        out[0] = point.x; out[1] = point.y; out[2] = point.z; out[3] = le.x; out[4] = le.y; out[5] = le.z;
+        out[6] = pdf; out[7] = (float)lobj;
+    } else if (a.op == kFnCameraRay) {
+        f3 o, d;
+        camera_ray(a.cam, w[2], w[0], w[1], o, d);
+        uint32_t dc[4];
+        philox4x32_10(w[2], kDepthCamera, 0u, 0u, w[0], w[1], dc);
+        out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z;
+        out[6] = u01(dc[0]); out[7] = u01(dc[1]);
     }
 }
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
+void PT_LAUNCH(launch_debug_fn)(const DebugFnArgs& a, hipStream_t st) {
+    if (a.n == 0u) return;
+    hipLaunchKernelGGL(k_debug_fn, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
+}
 void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, uint32_t accel, const float* rays6, uint32_t n, float t_min,
-                                 float t_max, float4* scratch, int32_t* out_id, float* out_t, hipStream_t st) {
+                                 float t_max, float4* scratch, int32_t* out_id, float* out_t, float* out_rec, hipStream_t st) {
     const int mode = scene_mode(sc, accel);
     const size_t lds = scene_lds_bytes(sc, mode);
     uint32_t grid = (n + kBlock - 1) / kBlock;
     if (grid > 2048u) grid = 2048u;
     if (grid == 0u) grid = 1u;
     if (mode == kModeLds)
-        hipLaunchKernelGGL(k_debug_hit<kModeLds>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
+        hipLaunchKernelGGL(k_debug_hit<kModeLds>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t, out_rec);
     else if (mode == kModeTiled)
-        hipLaunchKernelGGL(k_debug_hit<kModeTiled>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t);
+        hipLaunchKernelGGL(k_debug_hit<kModeTiled>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t, out_rec);
     else   // scratch: 3 planes of n float4 (two ray planes + result)
         hipLaunchKernelGGL(k_debug_hit_bvh, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, scratch,
-                           scratch + n, scratch + 2 * (size_t)n, out_id, out_t);
+                           scratch + n, scratch + 2 * (size_t)n, out_id, out_t, out_rec);
 }
 
 }  // namespace ptk

@@ -1,9 +1,9 @@
-//! Raw declarations of `include/pathtrace_amd.h` (ABI version 1).  Field order, types and names follow the
+//! Raw declarations of `include/pathtrace_amd.h` (ABI version 2).  Field order, types and names follow the
 //! header exactly; `tests/test_rust_binding.py` checks that.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const PT_ABI_VERSION: u32 = 1;
+pub const PT_ABI_VERSION: u32 = 2;
 
 pub const PT_OK: c_int = 0;
 pub const PT_ERR_INVALID_ARG: c_int = 1;
@@ -61,6 +61,16 @@ pub struct PtRenderParams {
     pub workgroups: u32,
     pub exact_math: u32,
     pub accel: u32,
+    pub n_devices: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtTuning {
+    pub export_below: u32,
+    pub bvh_refill: u32,
+    pub bvh_leaf: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -85,6 +95,13 @@ pub struct PtStats {
 pub struct PtContext {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct PtMulti {
+    _private: [u8; 0],
+}
+
+/// `pt_context_set_stream`: HIP's legacy default stream (its handle, 0, means "the context's own stream").
+pub const PT_STREAM_LEGACY_DEFAULT: usize = 1;
 
 pub type PtProgressFn = Option<
     unsafe extern "C" fn(user: *mut c_void, spp_done: u32, spp_total: u32, rgba8: *const u8, linear_rgb: *const f32) -> c_int,
@@ -99,6 +116,7 @@ extern "C" {
     pub fn pt_context_create(device: c_int, out: *mut *mut PtContext) -> c_int;
     pub fn pt_context_destroy(ctx: *mut PtContext) -> c_int;
     pub fn pt_context_set_stream(ctx: *mut PtContext, hip_stream: *mut c_void) -> c_int;
+    pub fn pt_context_set_tuning(ctx: *mut PtContext, tuning: *const PtTuning) -> c_int;
     pub fn pt_scene_upload(ctx: *mut PtContext, objs: *const PtObject, n_objs: u32) -> c_int;
     pub fn pt_render_device(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
     pub fn pt_sync(ctx: *mut PtContext) -> c_int;
@@ -106,7 +124,25 @@ extern "C" {
     pub fn pt_render_host(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render_progressive(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, spp_step: u32, f: PtProgressFn, user: *mut c_void, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render(cam: *const PtCamera, objs: *const PtObject, n_objs: u32, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_shutdown();
+    pub fn pt_multi_create(devices: *const c_int, n_devices: u32, out: *mut *mut PtMulti) -> c_int;
+    pub fn pt_multi_destroy(m: *mut PtMulti) -> c_int;
+    pub fn pt_multi_device_count(m: *const PtMulti) -> u32;
+    pub fn pt_multi_scene_upload(m: *mut PtMulti, objs: *const PtObject, n_objs: u32) -> c_int;
+    pub fn pt_multi_render_device(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
+    pub fn pt_multi_sync(m: *mut PtMulti) -> c_int;
+    pub fn pt_multi_get_stats(m: *mut PtMulti, out: *mut PtStats) -> c_int;
+    pub fn pt_multi_render_host(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_render_multi(devices: *const c_int, n_devices: u32, cam: *const PtCamera, objs: *const PtObject, n_objs: u32, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_render_pixels(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, xy: *const u32, n: u32, out_linear_rgb: *mut f32, out_rgba8: *mut u8, out_samples: *mut f32) -> c_int;
+    pub fn pt_ray_color(ctx: *mut PtContext, params: *const PtRenderParams, rays: *const f64, xy: *const u32, n: u32, out_rgb: *mut f32) -> c_int;
     pub fn pt_debug_hit_scene(ctx: *mut PtContext, rays: *const f64, n: u32, t_min: f64, t_max: f64, exact_math: u32, accel: u32, out_id: *mut i32, out_t: *mut f32) -> c_int;
+    pub fn pt_debug_hit_records(ctx: *mut PtContext, rays: *const f64, n: u32, t_min: f64, t_max: f64, exact_math: u32, accel: u32, out_id: *mut i32, out_rec: *mut f32) -> c_int;
+    pub fn pt_debug_bsdf_eval(ctx: *mut PtContext, obj: u32, in10: *const f64, n: u32, exact_math: u32, out4: *mut f32) -> c_int;
+    pub fn pt_debug_bsdf_sample(ctx: *mut PtContext, obj: u32, in7: *const f64, words4: *const u32, n: u32, exact_math: u32, out8: *mut f32) -> c_int;
+    pub fn pt_debug_shape_sample(ctx: *mut PtContext, obj: u32, from3: *const f64, target3: *const f64, r12: *const f64, n: u32, exact_math: u32, out8: *mut f32) -> c_int;
+    pub fn pt_debug_light_point(ctx: *mut PtContext, from3: *const f64, words4: *const u32, n: u32, exact_math: u32, out8: *mut f32) -> c_int;
+    pub fn pt_debug_camera_rays(ctx: *mut PtContext, cam: *const PtCamera, xys: *const u32, n: u32, exact_math: u32, out8: *mut f32) -> c_int;
     pub fn pt_debug_bvh_check(objs: *const PtObject, n_objs: u32, depth: *mut u32, n_nodes: *mut u32, n_leaf_slots: *mut u32) -> c_int;
     pub fn pt_last_error() -> *const c_char;
     pub fn pt_abi_version() -> u32;

@@ -201,17 +201,19 @@ def test_full_size_c4_bvh_film_equals_linear_scan_film(pt, gpu_ctx):
     assert np.isfinite(out[0][0]).all()
 
 
-def test_bvh_film_does_not_depend_on_traversal_scheduling(pt, gpu_ctx, monkeypatch):
+def test_bvh_film_does_not_depend_on_traversal_scheduling(pt, gpu_ctx):
     """Which lane traces which ray (refill threshold, leaf batching, number of queue segments) must not matter."""
     gpu_ctx.upload(pt.builtin_scene(4, 3000))
     cam = pt.camera_new(width=256, height=128)
     ref, ref8 = gpu_ctx.render(cam, pt.default_params(spp=8, accel=1))
     ref, ref8 = ref.cpu().numpy(), ref8.cpu().numpy()
-    for refill, leaf, wg in [("1", "1", 0), ("64", "64", 0), ("20", "3", 0), ("36", "24", 7), ("50", "40", 999)]:
-        monkeypatch.setenv("PT_BVH_REFILL", refill)
-        monkeypatch.setenv("PT_BVH_LEAF", leaf)
-        lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=8, accel=1, workgroups=wg))
-        assert np.array_equal(lin.cpu().numpy(), ref) and np.array_equal(rgba.cpu().numpy(), ref8), (refill, leaf, wg)
+    try:
+        for refill, leaf, wg in [(1, 1, 0), (64, 64, 0), (20, 3, 0), (36, 24, 7), (50, 40, 999)]:
+            gpu_ctx.set_tuning(bvh_refill=refill, bvh_leaf=leaf)          # pt_context_set_tuning
+            lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=8, accel=1, workgroups=wg))
+            assert np.array_equal(lin.cpu().numpy(), ref) and np.array_equal(rgba.cpu().numpy(), ref8), (refill, leaf, wg)
+    finally:
+        gpu_ctx.set_tuning()
 
 
 @pytest.mark.parametrize("t_min", [0.3, 0.05, 1e-6])

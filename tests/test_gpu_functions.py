@@ -1,0 +1,337 @@
+"""Function-level GPU parity: the per-vertex DEVICE functions of the path kernels -- not images --
+called through the C ABI (pt_debug_*) on the committed fixtures of tests/golden and on seeded inputs.
+
+  * default and exact arithmetic vs the f64 reference-faithful oracle / the committed f64 fixtures:
+    |d pdf|, |d f| <= 1e-4 relative (1e-3 for Mirror), same branch decisions;
+  * exact arithmetic vs the f32 oracle: bit for bit.
+
+Rows covered: a3 camera, a4/a5/a6/a7 hit records, a9 sample_light_point, a10/a11 shape sampling, a12-a15 the four
+materials (eval and sample), a8 ray_color on arbitrary rays, a2 render_pixel on a pixel list."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+F64, F32, REC, ITER = 64, 32, 0, 1
+
+MATS = {
+    "lambert": (0, [0.8, 0.6, 0.2]),
+    "emissive": (1, [15, 15, 15]),
+    "glass": (2, [0.3, 1, 1, 1, 0.0, 1.5]),
+    "metal": (2, [0.2, 0.9, 0.7, 0.3, 1.0, 1.5]),
+    "oren_nayar": (3, [0.7, 0.7, 0.7, 0.5]),
+}
+SHAPES = {"sphere": (0, [0.0, 0.79, -2.0, 0.2], [36] * 3),
+          "triangle": (1, [-0.3, 0.99, -2.3, 0.3, 0.99, -2.3, 0.3, 0.99, -1.7], [15] * 3)}
+
+
+def _close(got, ref, rtol, atol):
+    """Rows where the f64 value is finite and moderate (the GGX lobes reach 1e8 at grazing angles, where a
+    relative 1e-3 of the input error is amplified without bound)."""
+    fin = np.isfinite(ref).all(1) & (np.abs(ref).max(1) < 1e6)
+    return np.allclose(got[fin], ref[fin], rtol=rtol, atol=atol), fin
+
+
+@pytest.mark.parametrize("name", list(MATS))
+def test_bsdf_eval_device_function(pt, orc, gpu_ctx, name):
+    """Material::bsdf_pdf (material.rs:86-91,139-148,221-265; mirror.rs:62-124,179-198) on the committed vectors."""
+    tag, params = MATS[name]
+    ob = pt.make_objects([(0, [0, 0, 0, 1], tag, params)])
+    gpu_ctx.upload(ob)
+    g = np.load(os.path.join(GOLDEN, f"bsdf_{name}.npz"))
+    rtol = 1e-3 if tag == 2 else 1e-4
+    for exact in (1, 0):
+        got = gpu_ctx.debug_bsdf_eval(0, g["eval_in"], exact_math=exact).astype(np.float64)
+        ok, fin = _close(got, g["eval_out"], rtol, 1e-5)
+        assert fin.mean() > 0.9 and ok, (name, exact)
+    ref32 = orc.bsdf_eval(ob, g["eval_in"], F32).astype(np.float32)
+    got = gpu_ctx.debug_bsdf_eval(0, g["eval_in"], exact_math=1)
+    assert np.array_equal(got, ref32, equal_nan=True), name
+
+
+@pytest.mark.parametrize("name", list(MATS))
+def test_bsdf_sample_device_function(pt, orc, gpu_ctx, name):
+    """Material::bsdf_pdf_sample (material.rs:29-40,93-122; mirror.rs:17-60,200-305) on the committed vectors:
+    direction, f, pdf, cos; the lobe decision (reflect / refract / failed sample) must agree with f64."""
+    tag, params = MATS[name]
+    ob = pt.make_objects([(0, [0, 0, 0, 1], tag, params)])
+    gpu_ctx.upload(ob)
+    g = np.load(os.path.join(GOLDEN, f"bsdf_{name}.npz"))
+    ref = g["sample_out"]
+    rtol = 1e-3 if tag == 2 else 1e-4
+    for exact in (1, 0):
+        got = gpu_ctx.debug_bsdf_sample(0, g["sample_in"], g["draws"], exact_math=exact).astype(np.float64)
+        # same lobe: the sampled direction lies on the same side of the surface, failed samples (pdf = 1, f = 0) agree
+        nrm = g["sample_in"][:, 3:6]
+        side_ref = np.sign((ref[:, 0:3] * nrm).sum(1)); side = np.sign((got[:, 0:3] * nrm).sum(1))
+        same = side_ref == side
+        assert same.mean() >= 0.99, (name, exact, same.mean())          # a Fresnel coin flip within 1e-7 of u may differ
+        assert np.allclose(got[same, 0:3], ref[same, 0:3], atol=5e-5), (name, exact)
+        ok, fin = _close(got[same][:, 3:8], ref[same][:, 3:8], rtol, 1e-5)
+        assert ok and fin.mean() > 0.9, (name, exact)
+    ref32 = orc.bsdf_sample(ob, g["sample_in"], g["draws"], F32).astype(np.float32)
+    got = gpu_ctx.debug_bsdf_sample(0, g["sample_in"], g["draws"], exact_math=1)
+    assert np.array_equal(got, ref32, equal_nan=True), name
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_shape_sample_device_function(pt, orc, gpu_ctx, name):
+    """Shape::sample_surface_from_point (shape.rs:91-145, 200-242): sampled point, solid-angle pdf, direction and
+    distance; and the look-ahead form (target given, no draws) that the MIS weight of rendering.rs:114-117 uses."""
+    st, sv, em = SHAPES[name]
+    ob = pt.make_objects([(st, sv, 1, em)])
+    gpu_ctx.upload(ob)
+    g = np.load(os.path.join(GOLDEN, f"light_{name}.npz"))
+    ref = g["sampled"]                      # point3 normal3 pdf dir3 dist
+    for exact in (1, 0):
+        got = gpu_ctx.debug_shape_sample(0, g["frm"], r12=g["r12"], exact_math=exact).astype(np.float64)
+        assert np.allclose(got[:, 0:3], ref[:, 0:3], atol=2e-5)
+        assert np.allclose(got[:, 3], ref[:, 6], rtol=1e-4)
+        assert np.allclose(got[:, 4:7], ref[:, 7:10], atol=2e-5) and np.allclose(got[:, 7], ref[:, 10], rtol=1e-4, atol=2e-5)
+        got_t = gpu_ctx.debug_shape_sample(0, g["frm"], target=ref[:, 0:3], exact_math=exact).astype(np.float64)
+        assert np.allclose(got_t[:, 0:3], ref[:, 0:3], atol=1e-6)                 # the point is handed back
+        assert np.allclose(got_t[:, 3], g["with_target"][:, 6], rtol=1e-4)
+    s32 = orc.shape_sample(ob, g["frm"], None, g["r12"], F32)
+    got = gpu_ctx.debug_shape_sample(0, g["frm"], r12=g["r12"], exact_math=1)
+    assert np.array_equal(got[:, 0:4], s32[:, [0, 1, 2, 6]].astype(np.float32))
+    assert np.array_equal(got[:, 4:8], s32[:, 7:11].astype(np.float32))
+
+
+@pytest.mark.parametrize("scene,arg", [(1, 0), (2, 0), (4, 300)])
+def test_sample_light_point_device_function(pt, orc, gpu_ctx, scene, arg):
+    """World::sample_light_point (world.rs:251-267): uniform pick by the index word, surface sample, pdf / n_lights,
+    emission -- 2 triangle lights (C1), one sphere light (C2), 3 sphere lights among 300 objects."""
+    objs = pt.builtin_scene(scene, arg)
+    gpu_ctx.upload(objs)
+    rng = np.random.default_rng(5 + scene)
+    n = 4096
+    frm = np.stack([rng.uniform(-0.9, 0.9, n), rng.uniform(-0.9, 0.5, n), rng.uniform(-2.9, -1.1, n)], 1)
+    words = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    ref = orc.light_point(objs, frm, words, F64)
+    for exact in (1, 0):
+        got = gpu_ctx.debug_light_point(frm, words, exact_math=exact).astype(np.float64)
+        assert np.array_equal(got[:, 7], ref[:, 7])                               # the same light object
+        assert np.array_equal(got[:, 3:6], ref[:, 3:6])                           # its emission
+        assert np.allclose(got[:, 0:3], ref[:, 0:3], atol=2e-5)
+        assert np.mean(np.isclose(got[:, 6], ref[:, 6], rtol=1e-4)) >= 0.999      # grazing triangle samples: pdf ~ 1/cos
+    ref32 = orc.light_point(objs, frm, words, F32).astype(np.float32)
+    assert np.array_equal(gpu_ctx.debug_light_point(frm, words, exact_math=1), ref32)
+    assert len(set(ref[:, 7])) == {1: 2, 2: 1, 4: 3}[scene]
+
+
+def test_camera_ray_device_function(pt, orc, gpu_ctx):
+    """Camera::get_ray_with_offset (camera.rs:139-147) with the jitter draws of world.rs:299: the ray of sample s of
+    pixel (x, y), for the reference camera and a look_at camera (camera.rs:94-130)."""
+    gpu_ctx.upload(pt.builtin_scene(2))
+    rng = np.random.default_rng(9)
+    for cam in (pt.camera_new(width=400, height=400), pt.camera_look_at((0.6, 0.3, 1.8), (0.0, -0.3, -2.0), (0, 1, 0), 96, 40, 40.0)):
+        n = 2000
+        xys = np.stack([rng.integers(0, cam.width, n), rng.integers(0, cam.height, n), rng.integers(0, 5000, n)], 1).astype(np.uint32)
+        off = np.array([[orc.u01(w) for w in orc.philox((int(s), 0xFFFFFFFF, 0, 0), (int(x), int(y)))[:2]] for x, y, s in xys])
+        # world.rs:299 hands get_ray_with_offset the flipped row HEIGHT-1-y
+        flipped = np.stack([xys[:, 0], cam.height - 1 - xys[:, 1]], 1)
+        ref = orc.camera_rays(cam, flipped, off, F64)
+        for exact in (1, 0):
+            got = gpu_ctx.debug_camera_rays(cam, xys, exact_math=exact).astype(np.float64)
+            assert np.array_equal(got[:, 6:8], off)                               # the uniforms are exact in f32
+            assert np.allclose(got[:, 0:6], ref, atol=3e-7)
+        ref32 = orc.camera_rays(cam, flipped, off, F32).astype(np.float32)
+        assert np.array_equal(gpu_ctx.debug_camera_rays(cam, xys, exact_math=1)[:, 0:6], ref32)
+
+
+@pytest.mark.parametrize("scene,arg,accel", [(1, 0, 0), (2, 0, 0), (4, 3000, 0), (4, 3000, 1)])
+def test_hit_records_device_function(pt, orc, gpu_ctx, scene, arg, accel):
+    """HitRecord of the closest hit (shape.rs:84-88,194-197; base.rs:19-33): point, face-forwarded normal,
+    front_face -- Shape::hit's whole return value, through the LDS scan, the tiled scan and the BVH."""
+    objs = pt.builtin_scene(scene, arg)
+    gpu_ctx.upload(objs)
+    rng = np.random.default_rng(21 + scene)
+    n = 20000
+    o = np.stack([rng.uniform(-0.95, 0.95, n), rng.uniform(-0.95, 0.95, n), rng.uniform(-2.9, 1.9, n)], 1)
+    rays = np.concatenate([o, rng.normal(size=(n, 3))], 1)
+    ids64, t64, pn64, ff64 = orc.hit_scene(objs, rays, 0.001, float("inf"), F64)
+    ids32, t32, pn32, ff32 = orc.hit_scene(objs, rays, 0.001, float("inf"), F32)
+    ids, rec = gpu_ctx.debug_hit_records(rays, exact_math=1, accel=accel)
+    assert np.array_equal(ids, ids32)
+    hit = ids >= 0
+    assert np.array_equal(rec[hit, 0], t32[hit].astype(np.float32))
+    assert np.array_equal(rec[hit, 1:7], pn32[hit].astype(np.float32)) and np.array_equal(rec[hit, 7] != 0, ff32[hit] != 0)
+    assert not rec[~hit].any()
+    for exact in (1, 0):
+        ids, rec = gpu_ctx.debug_hit_records(rays, exact_math=exact, accel=accel)
+        same = (ids == ids64) & (ids >= 0)
+        assert same.sum() >= 0.999 * (ids64 >= 0).sum()
+        assert np.mean(np.abs(rec[same, 1:4] - pn64[same, 0:3]).max(1) <= 1e-4) >= 0.999          # point
+        assert np.mean(np.abs(rec[same, 4:7] - pn64[same, 3:6]).max(1) <= 2e-3) >= 0.995          # normal (R = 0.005 spheres: 1/r amplifies)
+        assert np.mean((rec[same, 7] != 0) == (ff64[same] != 0)) >= 0.9999
+
+
+# ---------------------------------------------------------------- World::render_pixel and ray_color through the ABI
+def test_pixel_replay_matches_the_full_film(pt, orc, gpu_ctx):
+    """The reference's own diagnostics replay single pixels of the 400 x 400 scene with the seed of main.rs:51
+    (world.rs:378 pixel (79, 176), world.rs:531 pixel (10, 158)).  pt_render_pixels = World::render_pixel for a pixel
+    list: every listed pixel must equal that pixel of the full film bit for bit (same key, same samples), in both
+    arithmetic modes and both integrators, and the per-sample radiance list (what the reference prints, world.rs:417)
+    must sum to the pixel and equal the f32 oracle's samples."""
+    objs = pt.builtin_scene(1)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_new(width=400, height=400)
+    rng = np.random.default_rng(1)
+    xy = np.array([[79, 176], [10, 158], [0, 0], [399, 399], [200, 37], [79, 176]] +
+                  [[int(rng.integers(0, 400)), int(rng.integers(0, 400))] for _ in range(300)], dtype=np.uint32)
+    spp = 32
+    for exact, integ in [(1, 0), (0, 0), (1, 1)]:
+        prm = pt.default_params(spp=spp, exact_math=exact, integrator=integ)
+        full, full8 = gpu_ctx.render(cam, prm)
+        full, full8 = full.cpu().numpy(), full8.cpu().numpy()
+        lin, rgba, smp = gpu_ctx.render_pixels(cam, prm, xy, want_samples=True)
+        assert np.array_equal(lin, full[xy[:, 1], xy[:, 0]]) and np.array_equal(rgba, full8[xy[:, 1], xy[:, 0]])
+        assert smp.shape == (len(xy), spp, 3)
+        assert np.array_equal((smp.astype(np.float64).sum(1) / spp).astype(np.float32), lin)      # world.rs:311-315, in sample order
+        # sample offsets address the same streams: samples 8..15 on their own
+        part, _, psmp = gpu_ctx.render_pixels(cam, pt.default_params(spp=8, spp_offset=8, exact_math=exact, integrator=integ), xy[:6], want_samples=True)
+        assert np.array_equal(psmp, smp[:6, 8:16])
+        if exact:
+            # the oracle's per-sample values: one-sample renders of the pixel's row
+            for (x, y) in xy[:2]:
+                for s in (0, 1, 17, 31):
+                    row, _, _ = orc.render(cam, objs, pt.default_params(spp=1, spp_offset=s, integrator=integ, band_rows=1,
+                                                                         band_index=int(y), band_count=400), F32, ITER, 1)
+                    i = int(np.argmax((xy[:, 0] == x) & (xy[:, 1] == y)))
+                    assert np.array_equal(smp[i, s], row[0, x].astype(np.float32)), (x, y, s)
+    # multi-batch lists (film sums across sample batches) give the same pixels; samples then cannot be returned
+    prm = pt.default_params(spp=spp, max_paths_in_flight=len(xy) * 5)
+    lin_b, rgba_b, _ = gpu_ctx.render_pixels(cam, prm, xy)
+    full, full8 = gpu_ctx.render(cam, pt.default_params(spp=spp))
+    assert np.array_equal(lin_b, full.cpu().numpy()[xy[:, 1], xy[:, 0]]) and gpu_ctx.stats().batches > 1
+    with pytest.raises(pt._lib.PtError, match="one sample batch"):
+        gpu_ctx.render_pixels(cam, prm, xy, want_samples=True)
+    with pytest.raises(pt._lib.PtError, match="outside"):
+        gpu_ctx.render_pixels(cam, prm, [[400, 0]])
+    lin0, rgba0, _ = gpu_ctx.render_pixels(cam, prm, np.zeros((0, 2), dtype=np.uint32))
+    assert lin0.shape == (0, 3)
+
+
+@pytest.mark.parametrize("scene,arg,accel", [(1, 0, 0), (2, 0, 0), (4, 2000, 0), (4, 2000, 1)])
+def test_pixel_list_through_every_scan(pt, gpu_ctx, scene, arg, accel):
+    """Pixel lists through the LDS scan, the tiled scan and the BVH kernels (their LIST variants)."""
+    gpu_ctx.upload(pt.builtin_scene(scene, arg))
+    cam = pt.camera_new(width=96, height=64)
+    prm = pt.default_params(spp=6, accel=accel)
+    full, full8 = gpu_ctx.render(cam, prm)
+    rng = np.random.default_rng(3)
+    xy = np.stack([rng.integers(0, 96, 700), rng.integers(0, 64, 700)], 1).astype(np.uint32)
+    lin, rgba, _ = gpu_ctx.render_pixels(cam, prm, xy)
+    assert np.array_equal(lin, full.cpu().numpy()[xy[:, 1], xy[:, 0]]) and np.array_equal(rgba, full8.cpu().numpy()[xy[:, 1], xy[:, 0]])
+
+
+@pytest.mark.parametrize("integrator", [0, 1])
+def test_ray_color_on_arbitrary_rays(pt, orc, gpu_ctx, integrator):
+    """RenderingStrategy::ray_color(world, ray, 0, rng, 1) (rendering.rs:34-142, 214-265) for rays that no camera
+    generated: exact arithmetic == the f32 oracle bit for bit; default arithmetic within tolerance of the f64
+    recursive (reference-faithful) form."""
+    objs = pt.builtin_scene(1)
+    gpu_ctx.upload(objs)
+    rng = np.random.default_rng(77)
+    n = 3000
+    o = np.stack([rng.uniform(-0.9, 0.9, n), rng.uniform(-0.9, 0.9, n), rng.uniform(-2.8, -1.2, n)], 1)
+    rays = np.concatenate([o, rng.normal(size=(n, 3)) * rng.uniform(0.1, 5.0, (n, 1))], 1)      # not normalised: Ray::new does it
+    xy = np.stack([rng.integers(0, 400, n), rng.integers(0, 400, n)], 1).astype(np.uint32)
+    prm = pt.default_params(spp=1, spp_offset=11, integrator=integrator, exact_math=1)
+    got = gpu_ctx.ray_color(prm, rays, xy)
+    ref32 = orc.ray_color(objs, prm, rays, xy, F32, ITER).astype(np.float32)
+    assert np.array_equal(got, ref32)
+    ref = orc.ray_color(objs, prm, rays, xy, F64, REC)
+    fast = gpu_ctx.ray_color(pt.default_params(spp=1, spp_offset=11, integrator=integrator), rays, xy).astype(np.float64)
+    ok = (np.abs(fast - ref) <= 1e-3 + 1e-2 * np.abs(ref)).all(1)
+    assert ok.mean() >= 0.99, ok.mean()                  # single samples: a branch flip is a whole different path
+    assert abs(fast.mean() - ref.mean()) <= 2e-2 * ref.mean()
+    # a ray that starts on a light and looks at it from outside the box sees Le (rendering.rs:43-45)
+    le = gpu_ctx.ray_color(prm, [[0.0, 0.5, -2.0, 0.0, 1.0, 0.0]], [[1, 1]])
+    assert np.array_equal(le, [[15.0, 15.0, 15.0]])
+
+
+# ---------------------------------------------------------------- the entry is asynchronous / graph-capturable
+def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx):
+    """pt_render_device enqueues and returns: no host synchronisation, no allocation once its buffers exist.  So it can
+    be captured into a hipGraph (torch.cuda.CUDAGraph on the stream the context renders on) and replayed; the film of
+    a replay is the film of a direct call.  1024 x 1024 x 8 spp = 8.4 M paths: large enough for the tail hand-off
+    (level-0 launch + continuation launch that reads its path count on the device)."""
+    import torch
+    objs = pt.builtin_scene(1)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_new(width=1024, height=1024)
+    prm = pt.default_params(spp=8)
+    ref, ref8 = gpu_ctx.render(cam, prm)                       # also creates every buffer of this size
+    st = gpu_ctx.stats()
+    assert st.bounce_launches == 2 and st.batches == 1
+    dev = torch.device("cuda", 0)
+    lin = torch.zeros_like(ref); rgba = torch.zeros_like(ref8)
+    stream = torch.cuda.Stream(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        gpu_ctx.set_stream(stream.cuda_stream)
+        with torch.cuda.graph(g, stream=stream):
+            gpu_ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
+        for _ in range(2):
+            lin.zero_(); rgba.zero_()
+            g.replay()
+            stream.synchronize()
+            assert torch.equal(lin, ref) and torch.equal(rgba, ref8)
+    gpu_ctx.set_stream(None)
+    del g
+
+
+def test_tuning_knobs_do_not_change_the_film(pt, gpu_ctx):
+    gpu_ctx.upload(pt.builtin_scene(1))
+    cam = pt.camera_new(width=1024, height=640)
+    prm = pt.default_params(spp=8)
+    ref, ref8 = gpu_ctx.render(cam, prm)
+    base = gpu_ctx.stats()
+    try:
+        for eb in (1, 16, 200):
+            gpu_ctx.set_tuning(export_below=eb)
+            lin, rgba = gpu_ctx.render(cam, prm)
+            st = gpu_ctx.stats()
+            assert torch_equal(lin, ref) and torch_equal(rgba, ref8)
+            assert (st.vertices, st.shadow_rays) == (base.vertices, base.shadow_rays)
+    finally:
+        gpu_ctx.set_tuning()
+
+
+def torch_equal(a, b):
+    import torch
+    return torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- multi-GPU behind the C ABI (one device here)
+def test_multi_gpu_entry_with_one_device_over_rccl(pt, gpu_ctx):
+    """pt_multi_*: contexts + ncclCommInitAll + ONE ncclGather of the packed film + row permutation, with the single
+    device of this box: the whole N-device code path over real RCCL.  The frame equals the single-context render
+    bit for bit, for several band heights (interleaved bands, ragged last band) and for the one-shot entries."""
+    objs = pt.builtin_scene(1)
+    cam = pt.camera_new(width=200, height=117)
+    prm = pt.default_params(spp=6)
+    gpu_ctx.upload(objs)
+    ref, ref8 = gpu_ctx.render(cam, prm)
+    ref, ref8 = ref.cpu().numpy(), ref8.cpu().numpy()
+    m = pt.Multi([0])
+    try:
+        m.upload(objs)
+        for band_rows in (0, 1, 7, 64, 500):
+            lin, rgba = m.render_host(cam, pt.default_params(spp=6, band_rows=band_rows))
+            assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8), band_rows
+        st = m.stats()
+        assert st.samples == 200 * 117 * 6
+    finally:
+        m.close()
+    lin, rgba = pt.render_multi([0], cam, objs, prm)
+    assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8)
+    lin, rgba = pt.render_host(cam, objs, pt.default_params(spp=6, n_devices=1))
+    assert np.array_equal(lin, ref)
+    with pytest.raises(pt._lib.PtError, match="twice"):
+        pt.Multi([0, 0])
+    pt._lib.lib().pt_shutdown()

@@ -7,6 +7,10 @@ namespace ptk {
 void launch_paths_exact(const BounceArgs&, uint32_t, hipStream_t) { std::abort(); }
 void launch_paths_fast(const BounceArgs&, uint32_t, hipStream_t) { std::abort(); }
 void launch_resolve(const ResolveArgs&, hipStream_t) { std::abort(); }
-void launch_debug_hit_exact(const SceneView&, uint32_t, const float*, uint32_t, float, float, float4*, int32_t*, float*, hipStream_t) { std::abort(); }
-void launch_debug_hit_fast(const SceneView&, uint32_t, const float*, uint32_t, float, float, float4*, int32_t*, float*, hipStream_t) { std::abort(); }
+void launch_debug_hit_exact(const SceneView&, uint32_t, const float*, uint32_t, float, float, float4*, int32_t*, float*, float*, hipStream_t) { std::abort(); }
+void launch_debug_hit_fast(const SceneView&, uint32_t, const float*, uint32_t, float, float, float4*, int32_t*, float*, float*, hipStream_t) { std::abort(); }
+void launch_debug_fn_exact(const DebugFnArgs&, hipStream_t) { std::abort(); }
+void launch_debug_fn_fast(const DebugFnArgs&, hipStream_t) { std::abort(); }
+void launch_film_pack(const float*, const uint8_t*, uint32_t, void*, hipStream_t) { std::abort(); }
+void launch_film_unpack(const void*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float*, uint8_t*, hipStream_t) { std::abort(); }
 }  // namespace ptk

@@ -6,6 +6,8 @@ import pathtrace_amd as pt
 def run(name, objs, W, H, spp, reps=2, **kw):
     cam = pt.camera_new(width=W, height=H); prm = pt.default_params(spp=spp, profile=1, **kw)
     ctx = pt.Context(0); ctx.upload(objs)
+    ctx.set_tuning(bvh_refill=int(os.environ.get("TUNE_BVH_REFILL", "0")), bvh_leaf=int(os.environ.get("TUNE_BVH_LEAF", "0")),
+                   export_below=int(os.environ.get("TUNE_EXPORT_BELOW", "0")))     # read by this script, not by the library
     best = None
     for _ in range(reps):
         t = time.time(); lin, rgba = ctx.render(cam, prm); dt = time.time() - t; st = ctx.stats()
