@@ -568,6 +568,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     a.pixels = list ? list->d_pixels : nullptr;
     a.film_w = list ? 65536u : cam->width;
     a.np = np;
+    auto magic = [](uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); };
+    a.film_w_magic = magic(a.film_w);
+    a.np_magic = magic(np);
     a.min_depth = prm->min_depth; a.max_depth = prm->max_depth;
     a.t_min = (float)prm->t_min;
     a.integrator = prm->integrator;
@@ -1042,9 +1045,9 @@ int pt_ray_color(PtContext* c, const PtRenderParams* prm, const double* rays, co
         float fslot, fsd;
         std::memcpy(&fslot, &slot, 4); std::memcpy(&fsd, &sd, 4);
         plane[0][i] = make_float4(o[0], o[1], o[2], d[0]);
-        plane[1][i] = make_float4(d[1], d[2], 1.0f, 1.0f);
-        plane[2][i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        plane[3][i] = make_float4(0.0f, 1.0f, fslot, fsd);      // pdf_prev 0, eta_ratio 1 (camera.rs:14)
+        plane[1][i] = make_float4(d[1], d[2], fslot, fsd);
+        plane[2][i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);      // throughput 1, pdf_prev 0
+        plane[3][i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);      // no radiance yet, eta_ratio 1 (camera.rs:14)
     }
     int rc;
     if ((rc = c->pixel_list.ensure(n))) return rc;

@@ -64,7 +64,20 @@ PT_DEV f3 cross(f3 a, f3 b) {                                                   
     return mk(msub(a.y, b.z, a.z, b.y), msub(a.z, b.x, a.x, b.z), msub(a.x, b.y, a.y, b.x));
 }
 PT_DEV float length(f3 a) { return pt_sqrt(dot(a, a)); }                     // math.rs:38
+#if PT_MATH_EXACT || !defined(PT_RSQ_NORMALIZE)
 PT_DEV f3 normalize(f3 a) { float len = length(a); return len > 0.0f ? a / len : a; }   // math.rs:48-51
+// to_light.length() and to_light.normalize() of the same vector (rendering.rs:59-60, shape.rs:218-221)
+PT_DEV f3 normalize_len(f3 a, float& len) { len = length(a); return len > 0.0f ? a / len : a; }
+#else
+// Fast arithmetic: ONE v_rsq_f32 (1 ulp) instead of sqrt + rcp + a compare and three selects.  A zero vector stays
+// zero as in math.rs:48-51: 0 * rsq(1e-36) = 0 (the clamp only ever acts on |a| < 1e-18).
+PT_DEV f3 normalize(f3 a) { return a * __builtin_amdgcn_rsqf(__builtin_fmaxf(dot(a, a), 1e-36f)); }
+PT_DEV f3 normalize_len(f3 a, float& len) {
+    const float l2 = dot(a, a), inv = __builtin_amdgcn_rsqf(__builtin_fmaxf(l2, 1e-36f));
+    len = l2 * inv;
+    return a * inv;
+}
+#endif
 PT_DEV float luminance(f3 a) { return 0.2126f * a.x + 0.7152f * a.y + 0.0722f * a.z; }  // math.rs:133
 PT_DEV bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 PT_DEV f3 madd(f3 a, float s, f3 b) {                                                // a*s + b
@@ -74,8 +87,13 @@ PT_DEV f3 madd(f3 a, float s, f3 b) {                                           
 PT_DEV f3 frame3(f3 t, float x, f3 b, float y, f3 n, float z) { return madd(n, z, madd(b, y, t * x)); }
 PT_DEV bool finite3(f3 v) { return __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z); }
 
-// sin/cos(2*pi*u), u in (0,1): quadrant reduction on u, cephes sinf/cosf kernels.
+// sin/cos(2*pi*u), u in (0,1): quadrant reduction on u, cephes sinf/cosf kernels.  Fast arithmetic: the hardware's
+// v_sin_f32 / v_cos_f32, which take their argument in revolutions (two instructions instead of ~25).
 PT_DEV void sincos2pi(float u, float& s, float& c) {
+#if !PT_MATH_EXACT && !defined(PT_NO_NATIVE_SINCOS)
+    s = __builtin_amdgcn_sinf(u); c = __builtin_amdgcn_cosf(u);
+    return;
+#endif
     float k = __builtin_rintf(u * 4.0f);
     float r = __builtin_fmaf(k, -0.25f, u);
     float t = r * 6.28318530717958647692f;
@@ -121,7 +139,9 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 enum { BLK_SURFACE = 0, BLK_CHOICE = 1 };
 constexpr uint32_t kDepthCamera = 0xFFFFFFFFu;
 // 23-bit uniform on the open interval (0,1): (2k+1)/2^24, exact in f32.
-PT_DEV float u01(uint32_t r) { return (float)(((r >> 9) << 1) | 1u) * (1.0f / 16777216.0f); }
+// Evaluated without an integer-to-float conversion: bits(1 + k/2^23) minus (1 - 2^-24); the sum is representable,
+// so the one rounding of the add is exact and the value is (2k+1)/2^24 bit for bit.
+PT_DEV float u01(uint32_t r) { return __uint_as_float((r >> 9) | 0x3F800000u) + (-0.99999994f); }
 
 // ------------------------------------------------------------------ scene records
 // shape record, 3 float4 per object:
@@ -236,8 +256,13 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 t
     f3 normal = normalize(cr);
     float area = length(cr) * 0.5f;
     f3 to_light = point - from;
+#if PT_MATH_EXACT || !defined(PT_RSQ_NORMALIZE)
     float d = length(to_light);
-    f3 light_dir = to_light / d;
+    f3 light_dir = to_light / d;                     // shape.rs:218-221
+#else
+    float d;
+    f3 light_dir = normalize_len(to_light, d);
+#endif
     float cos_light = __builtin_fabsf(dot(normal, -light_dir));
     float pdf_area = pt_rcp(area);
     pdf_omega = cos_light > 1e-8f ? pt_div(pdf_area * (d * d), cos_light) : 1e-8f;

@@ -47,10 +47,10 @@ struct CameraF {             // Camera's cached fields in f32 (camera.rs:36-38)
 };
 
 // Path-state queue: 4 float4 planes, index = queue slot (coalesced 16 B/lane).
-//   q0 = (o.x, o.y, o.z, d.x)  q1 = (d.y, d.z, beta.x, beta.y)
-//   q2 = (beta.z, L.x, L.y, L.z)
-//   q3 = (pdf_prev, eta_in, bits(tile_row<<16 | x), bits(s_local<<16 | depth))
-// so width, tile rows and samples per batch are each < 65536.
+//   ray part    q0 = (o.x, o.y, o.z, d.x)   q1 = (d.y, d.z, bits(tile_row<<16 | x), bits(s_local<<16 | depth))
+//   carry part  q2 = (beta.x, beta.y, beta.z, pdf_prev)   q3 = (L.x, L.y, L.z, eta_in)
+// so width, tile rows and samples per batch are each < 65536.  The kernels read the carry part of a path only after
+// its vertex's scans (it is not needed before), which keeps eight registers free during them.
 struct Queue {
     float4* q[4];
 };
@@ -90,7 +90,9 @@ struct BounceArgs {
     // (camera width, or 65536 for a list).
     const uint2* pixels;
     uint32_t film_w;
+    uint32_t film_w_magic;    // floor(2^32 / film_w), 0xFFFFFFFF for 1 (divmod_magic)
     uint32_t np;              // pixels of the tile
+    uint32_t np_magic;        // floor(2^32 / np), 0xFFFFFFFF for 1
     uint32_t s_base;          // sample index of s_local = 0 (spp_offset + batch start)
     uint32_t min_depth, max_depth;
     float t_min;

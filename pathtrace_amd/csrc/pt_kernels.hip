@@ -237,6 +237,18 @@ PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max
 PT_DEV f3 parked_origin() { return mk(3e18f, 3e18f, 3e18f); }
 PT_DEV f3 parked_dir() { return mk(1.0f, 0.0f, 0.0f); }
 
+// number of set bits of a wave mask below this lane (v_mbcnt: no lane-mask registers to keep)
+PT_DEV uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// n / d and n % d for n < 2^32 with the host's magic = floor(2^32 / d) (d >= 2; 0xFFFFFFFF for d = 1): umulhi is at
+// most one below the quotient.  Replaces the compiler's division sequence, whose reciprocals sat in VGPRs for the
+// whole kernel.
+PT_DEV void divmod_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t& q, uint32_t& r) {
+    q = __umulhi(n, magic);
+    r = n - q * d;
+    if (r >= d) { q += 1u; r -= d; }
+}
 // tile row -> image row (TileMap)
 PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
     uint32_t q = t.band_rows == 1u ? yl : __umulhi(yl, t.band_magic);
@@ -262,24 +274,35 @@ struct Vertex {
     uint32_t w_bsdf1, w_bsdf2;   // the vertex's BSDF words of BLK_SURFACE (drawn together with the light words)
     uint32_t w_lobe, w_rr;       // its BLK_CHOICE words, when vertex_begin had to draw that block (several lights)
     int obj, light_obj;          // object hit (>= 0) and light picked: vertex_end can re-read their records (REMAT)
+    bool hit_emitter;            // the path ray reached an emitter: vertex_end credits it (it needs the carry state)
+    float emit_pdf_shape;        // ... with the light pdf of that point seen from the previous vertex (MIS, depth > 0)
 };
 
-PT_DEV PathState unpack_state(float4 q0, float4 q1, float4 q2, float4 q3) {
-    PathState p;
+// Queue planes (pt_kernels.h): the RAY part of the state -- what the closest-hit scan and the light sample need --
+// is planes 0 and 1; the CARRY part -- throughput, radiance so far, the previous sampling pdf, the incoming eta --
+// is planes 2 and 3 and is only looked at once the vertex's scans are through (k_paths loads it that late, so those
+// eight values do not occupy registers during the scans).
+PT_DEV void unpack_ray(PathState& p, float4 q0, float4 q1) {
     p.o = mk(q0.x, q0.y, q0.z); p.d = mk(q0.w, q1.x, q1.y);
-    p.beta = mk(q1.z, q1.w, q2.x); p.L = mk(q2.y, q2.z, q2.w);
-    p.pdf_prev = q3.x; p.eta_in = q3.y;
-    const uint32_t xy = __float_as_uint(q3.z), sd = __float_as_uint(q3.w);
+    const uint32_t xy = __float_as_uint(q1.z), sd = __float_as_uint(q1.w);
     p.yl = xy >> 16; p.px = xy & 0xFFFFu;
     p.s_local = sd >> 16; p.depth = sd & 0xFFFFu;
+}
+PT_DEV void unpack_carry(PathState& p, float4 q2, float4 q3) {
+    p.beta = mk(q2.x, q2.y, q2.z); p.pdf_prev = q2.w;
+    p.L = mk(q3.x, q3.y, q3.z); p.eta_in = q3.w;
+}
+PT_DEV PathState unpack_state(float4 q0, float4 q1, float4 q2, float4 q3) {
+    PathState p;
+    unpack_ray(p, q0, q1);
+    unpack_carry(p, q2, q3);
     return p;
 }
 PT_DEV void store_state(const Queue& q, uint32_t j, const PathState& p) {
     q.q[0][j] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
-    q.q[1][j] = make_float4(p.d.y, p.d.z, p.beta.x, p.beta.y);
-    q.q[2][j] = make_float4(p.beta.z, p.L.x, p.L.y, p.L.z);
-    q.q[3][j] = make_float4(p.pdf_prev, p.eta_in, __uint_as_float((p.yl << 16) | p.px),
-                            __uint_as_float((p.s_local << 16) | p.depth));
+    q.q[1][j] = make_float4(p.d.y, p.d.z, __uint_as_float((p.yl << 16) | p.px), __uint_as_float((p.s_local << 16) | p.depth));
+    q.q[2][j] = make_float4(p.beta.x, p.beta.y, p.beta.z, p.pdf_prev);
+    q.q[3][j] = make_float4(p.L.x, p.L.y, p.L.z, p.eta_in);
 }
 PT_DEV PathState parked_state() {
     PathState p;
@@ -319,7 +342,8 @@ PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, ui
     pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);  // world.rs:260 (x/1 == x)
 }
 
-// (id, t) = closest hit of the path ray, id < 0: miss.  Credits an emitter hit into p.L and samples the light point.
+// (id, t) = closest hit of the path ray, id < 0: miss.  Notes an emitter hit and samples the light point.  Reads only the
+// RAY part of p (origin, direction, depth, film position).
 // DIFFUSE: the scene has Lambertian and emissive materials only (decided at pt_scene_upload); the GGX and
 // OrenNayar code is then compiled out of the kernel (same results; smaller code, no spills at 6 waves/SIMD: C2 +2 %).
 // (kx, py) = the pixel's RNG key (main.rs:51); it is the path's film position except in pixel-list renders.
@@ -328,6 +352,7 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
                          uint32_t py, Vertex& v) {
     v.alive = active && id >= 0;
     v.obj = id >= 0 ? id : 0; v.light_obj = 0;
+    v.hit_emitter = false; v.emit_pdf_shape = 0.0f;
     v.hit.point = p.o; v.hit.normal = p.d; v.hit.t = 0.0f; v.hit.front_face = false;
     v.m.tag = MAT_LAMBERT; v.m.shape_tag = 0; v.m.emits = 0; v.m.color = mk(0.f, 0.f, 0.f);
     v.m.roughness = 0.f; v.m.metallic = 0.f; v.m.ior = 1.f; v.m.on_a = 1.f; v.m.on_b = 0.f;
@@ -336,15 +361,12 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
         if (DIFFUSE) __builtin_assume(v.m.tag <= MAT_EMISSIVE);
         v.hit = finish_hit(sc.shape, id, v.m.shape_tag, p.o, p.d, t);
         if (v.m.emits) {
-            if (!MIS || p.depth == 0u) {
-                p.L = p.L + p.beta * v.m.color;                                   // rendering.rs:44-45 / :225-227
-            } else {
-                // emitter reached by a BSDF-sampled ray: MIS weight against the light
-                // pdf seen from the previous vertex = this ray's origin (rendering.rs:107-121)
-                f3 sp; float pdf_shape;
-                shape_sample(sc.shape, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, pdf_shape);
-                float w_bsdf = pt_div(p.pdf_prev, p.pdf_prev + pdf_shape);             // :117 (Q2: not / n_lights)
-                p.L = p.L + p.beta * v.m.color * w_bsdf;
+            v.hit_emitter = true;
+            if (MIS && p.depth != 0u) {
+                // emitter reached by a BSDF-sampled ray: its MIS weight (vertex_end) is against the light pdf of
+                // this point seen from the previous vertex = this ray's origin (rendering.rs:107-116)
+                f3 sp;
+                shape_sample(sc.shape, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, v.emit_pdf_shape);
             }
             v.alive = false;
         }
@@ -369,8 +391,7 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
             f3 lp;
             sample_light_point<DIFFUSE>(sc, v.hit.point, w_index, ds[0], ds[1], lp, v.light_obj, v.ls_emission, v.ls_pdf);
             f3 to_light = lp - v.hit.point;                                       // rendering.rs:58-60
-            v.distance = length(to_light);
-            v.light_dir = normalize(to_light);
+            v.light_dir = normalize_len(to_light, v.distance);
             v.need_shadow = true;
         }
     }
@@ -392,6 +413,14 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
         v.ls_emission = load_mat(sc.mat, vin.light_obj).color;
     }
     if (DIFFUSE) __builtin_assume(v.m.tag <= MAT_EMISSIVE);
+    if (vin.hit_emitter) {
+        if (!MIS || p.depth == 0u) {
+            p.L = p.L + p.beta * v.m.color;                                       // rendering.rs:44-45 / :225-227
+        } else {
+            float w_bsdf = pt_div(p.pdf_prev, p.pdf_prev + vin.emit_pdf_shape);   // :117 (Q2: not / n_lights)
+            p.L = p.L + p.beta * v.m.color * w_bsdf;                              // :119-121
+        }
+    }
     f3 direct = mk(0.f, 0.f, 0.f);
     if (MIS && visible) {
         float cos_theta = __builtin_fabsf(dot(v.hit.normal, v.light_dir));    // rendering.rs:68
@@ -539,12 +568,11 @@ k_paths(BounceArgs a) {
             if (active) {
                 if (from_overflow) {
                     // continuation launch: the paths are the leftovers an earlier launch exported
-                    p = unpack_state(a.ovf_in.q[0][pid], a.ovf_in.q[1][pid], a.ovf_in.q[2][pid], a.ovf_in.q[3][pid]);
+                    unpack_ray(p, a.ovf_in.q[0][pid], a.ovf_in.q[1][pid]);
                 } else {
-                    p.s_local = pid / a.np;
-                    const uint32_t pix = pid - p.s_local * a.np;
-                    p.yl = pix / W;
-                    p.px = pix - p.yl * W;
+                    uint32_t pix;
+                    divmod_magic(pid, a.np, a.np_magic, p.s_local, pix);
+                    divmod_magic(pix, W, a.film_w_magic, p.yl, p.px);
                 }
             }
         } else {
@@ -552,7 +580,7 @@ k_paths(BounceArgs a) {
             // lane without a path only needs a ray that hits nothing -- its other fields are never looked at)
             active = it * chunk_slots + lane_off < n_in;
             const uint32_t s0 = seg_base + it * chunk_slots + lane_off;
-            p = unpack_state(a.q.q[0][s0], a.q.q[1][s0], a.q.q[2][s0], a.q.q[3][s0]);
+            unpack_ray(p, a.q.q[0][s0], a.q.q[1][s0]);
             if (!active) { p.o = parked_origin(); p.d = parked_dir(); }
         }
         uint32_t kx, py;                                  // key of the path's RNG stream = (x, y), main.rs:51
@@ -560,6 +588,17 @@ k_paths(BounceArgs a) {
         const uint32_t sample = a.s_base + p.s_local;
 
         if (first && !from_overflow && active) camera_ray(a.cam, sample, kx, py, p.o, p.d);
+        // the CARRY part of the state (throughput, radiance, previous pdf, incoming eta) of the slot this lane works on
+        auto load_carry = [&]() {
+            if (!first || from_overflow) {
+                const Queue& src = first ? a.ovf_in : a.q;
+                const uint32_t s1 = first ? (it * nw + wave) * 64u + lane : seg_base + it * chunk_slots + lane_off;
+                if (!first || active) unpack_carry(p, src.q[2][s1], src.q[3][s1]);
+            }
+        };
+#ifdef PT_EARLY_CARRY
+        load_carry();
+#endif
 
         wave_vertices += (uint32_t)__popcll(__ballot(active));
         // deepest vertex: in a level-0 launch every path of pass p is at depth p; only a continuation launch
@@ -593,6 +632,12 @@ k_paths(BounceArgs a) {
                 wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
         }
+        // ---- the carry part only now: none of it was needed -- or occupied a register -- during the two scans.
+        // (The compiler barrier keeps the loads down here.)
+#ifndef PT_EARLY_CARRY
+        asm volatile("" ::: "memory");
+        load_carry();
+#endif
         const bool alive = vertex_end<MIS, DIFFUSE, SMALL>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
 
         // ---- retire, or compact in place into the wave's own segment
@@ -607,7 +652,7 @@ k_paths(BounceArgs a) {
             cnt_all = 0;
             for (uint32_t k = 0; k < kBlock / 64; ++k) { cnt_before += k < wib ? s_iters[k] : 0u; cnt_all += s_iters[k]; }
         }
-        if (alive) store_state(a.q, seg_base + out_n + cnt_before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+        if (alive) store_state(a.q, seg_base + out_n + cnt_before + lane_rank(mask), p);
         out_n += cnt_all;
     }
     n_in = out_n;
@@ -830,10 +875,9 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             if (OVF) {
                 p = unpack_state(a.ovf_in.q[0][pid], a.ovf_in.q[1][pid], a.ovf_in.q[2][pid], a.ovf_in.q[3][pid]);
             } else {
-                p.s_local = pid / a.np;
-                const uint32_t pix = pid - p.s_local * a.np;
-                p.yl = pix / W;
-                p.px = pix - p.yl * W;
+                uint32_t pix;
+                divmod_magic(pid, a.np, a.np_magic, p.s_local, pix);
+                divmod_magic(pix, W, a.film_w_magic, p.yl, p.px);
                 uint32_t kx, py;
                 pixel_key<LIST>(a, p, kx, py);
                 camera_ray(a.cam, a.s_base + p.s_local, kx, py, p.o, p.d);
@@ -856,7 +900,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 const bool active = s < n_in;
                 PathState p = parked_state();
                 float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-                if (active) { p = unpack_state(q.q[0][s], q.q[1][s], make_float4(0.f, 0.f, 0.f, 0.f), q.q[3][s]); h = aux[s]; }
+                if (active) { unpack_ray(p, q.q[0][s], q.q[1][s]); h = aux[s]; }
                 Vertex v;
                 uint32_t kx, py;
                 pixel_key<LIST>(a, p, kx, py);
@@ -897,7 +941,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             const bool alive = vertex_end<MIS, DIFFUSE, false>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
             if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
             const unsigned long long mask = __ballot(alive);
-            if (alive) store_state(q, out_n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+            if (alive) store_state(q, out_n + lane_rank(mask), p);
             out_n += (uint32_t)__popcll(mask);
         }
         n_in = out_n;
