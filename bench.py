@@ -11,14 +11,18 @@ RCCL gather of the framebuffer to rank 0.  Scene and camera are resident in HBM
 before the timed region; outputs stay in HBM (no PCIe in the timed region).
 
 Workload (BASELINE.json configs[1]): 10-sphere diffuse Cornell scene ("C2"),
-1024x1024, 64 spp, MIS integrator, reference path-depth policy.  N > 1 is WEAK scaling:
-the image stays 1024x1024 and the sample count grows to 64*N spp, rows are dealt to
-the ranks in interleaved bands, so every rank traces exactly the N = 1 number of
-samples (1024*1024*64) and the gathered frame is still 1024x1024.
+1024x1024, 64 spp, MIS integrator, reference path-depth policy.  N > 1 is STRONG scaling, as
+BASELINE.json's metric asks ("at 1024^2/64spp, 1/2/4/8 GPU"): the job stays 1024x1024x64 spp,
+its rows are dealt to the ranks in interleaved bands and ONE gather per step assembles the
+frame on rank 0.  `--workload c5` is the configuration built for 8 GPUs (3840x2160x1024 spp).
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (k_bounce)
-with the ALGORITHMIC bytes of SURVEY 8(d): 252 B per path vertex + 64 B per camera
-sample, divided by the HIP-event time of the bounce launches measured in this run.
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the level-0 launch
+of k_paths) against what bounds it: the f32 VALU (bound "valu": there is no dense contraction
+on this path, so the schema's "mfma" slot does not apply; the peak is the same 157.3 TFLOP/s
+f32 rate).  achieved = ALGORITHMIC flops of SURVEY 8(d) -- F_isect per primitive test of every
+scan the launch ran (23 per sphere, 51 per triangle) + 200 per path vertex -- divided by the
+HIP-event time of those launches measured in this run.  `hbm_frac` and `valu_issue_frac` come
+from the committed rocprofv3 counter passes of the same command and carry their source file.
 `cpu_baseline` times the oracle (CPU restatement of the reference, f64 recursive,
 std::thread over pixels like rayon) on a bounded sample of the same workload; the
 Rust reference itself cannot be built here or on the GPU box (no cargo/rustc).
@@ -44,9 +48,12 @@ WORKLOADS = {
     "c4": (4, 10000, 1024, 1024, 256, "C4: 10 000 random spheres (100 lights)"),
     "c5": (2, 0, 3840, 2160, 1024, "C5: 10-sphere diffuse Cornell scene, 4K"),
 }
-BYTES_PER_VERTEX = 252      # extend 32 + shade 144 + shadow/accumulate 68 + compaction 8
-BYTES_PER_SAMPLE = 64       # ray generation 52 + final radiance 12
+BYTES_PER_VERTEX = 252      # extend 32 + shade 144 + shadow/accumulate 68 + compaction 8 (a five-kernel pipeline;
+BYTES_PER_SAMPLE = 64       # the fused kernel never makes those round trips: informational only)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
+VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (= the f32 MFMA rate)
+F_SPHERE, F_TRIANGLE, F_SHADE = 23, 51, 200     # flops per primitive test / per shaded vertex (Lambert)
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
 def cpu_baseline(pt, objs):
@@ -96,31 +103,22 @@ def cpu_baseline(pt, objs):
     }
 
 
-def pmc_valu(world, workload="c2"):
-    """VALU issue figures of the same kernel from the same profile file (static, like `traffic`): the kernel is
-    VALU-bound, which the hbm|mfma `bound` field cannot say."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    if world != 1 or workload != "c2" or not os.path.exists(path):
+def profile_summary(world, workload, accel):
+    """Counter-derived figures of the dominant kernel from the committed rocprofv3 passes of THIS command
+    (profiles/r02/roofline_<workload>[_bvh].json, written by tools/profile_workload.sh on the GPU box).  PMC counters
+    cannot be read from inside this process, so these are the last profiled values, tagged with their source file;
+    None when no profile of this exact workload exists (or N > 1)."""
+    if world != 1:
+        return None
+    name = f"roofline_{workload}{'_bvh' if accel == 1 else ''}.json"
+    path = os.path.join(PROFILE_DIR, name)
+    if not os.path.exists(path):
         return None
     try:
         with open(path) as f:
-            v = json.load(f).get("valu")
-        return {k: v[k] for k in ("insts_per_launch", "cycles_per_inst_per_simd", "ubench_cycles_per_inst", "frac_of_ubench_rate")} if v else None
-    except Exception:
-        return None
-
-
-def pmc_traffic(world, workload="c2"):
-    """HBM bytes per k_paths launch from the committed rocprofv3 PMC passes (profiles/r01/traffic.json:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command, tools/profile_gpu.sh).
-    PMC counters cannot be read from inside this process, so the figure is the last profiled one for this
-    exact workload (N = 1); null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    if world != 1 or workload != "c2" or not os.path.exists(path):
-        return None
-    try:
-        d = json.load(open(path))
-        return int(d["hbm_bytes_per_launch"]) if d.get("workload") == "C2 1024x1024x64" else None
+            d = json.load(f)
+        d["_file"] = os.path.relpath(path, ROOT)
+        return d
     except Exception:
         return None
 
@@ -134,8 +132,10 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0, help="PtRenderParams.max_paths_in_flight (0 = default)")
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--accel", type=int, default=0, choices=[0, 1],
-                    help="PtRenderParams.accel: 0 = the reference's linear scan (every reported config), 1 = BVH (same film)")
+    ap.add_argument("--accel", type=int, default=0, choices=[0, 1, 2],
+                    help="PtRenderParams.accel: 0 = the reference's linear scan (every reported config), 1 = BVH (same film), "
+                         "2 = PT_ACCEL_AUTO, the product default (the BVH for C4-sized scenes)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (64*N spp) instead of the strong-scaling default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
                          "goes through host memory); the driver's runs use nccl (RCCL)")
@@ -175,7 +175,7 @@ def main():
         args.no_cpu_baseline = True          # the CPU baseline leg is defined on the headline config
     objs = pt.builtin_scene(scene_id, scene_arg)
     cam = pt.camera_new(width=WIDTH, height=HEIGHT)
-    spp = SPP * world
+    spp = SPP * world if args.weak else SPP
     band_rows = default_band_rows(HEIGHT, world) if multi else 0
     prm = pt.default_params(spp=spp, band_rows=band_rows, band_index=rank, band_count=world, profile=1,
                             max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
@@ -187,7 +187,7 @@ def main():
     rgba = torch.empty((rows, WIDTH, 4), dtype=torch.uint8, device=dev)
 
     acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0,
-           "p_vertices": 0, "p_ms": 0.0, "p_launches": 0}
+           "p_vertices": 0, "p_ms": 0.0, "p_launches": 0, "shadow_rays": 0}
 
     # the single exchange step of the path: one gather of the framebuffer (f32 + RGBA8 packed) per step.  It is
     # launched asynchronously, so the gather of step k runs (on the backend's stream) while step k + 1 renders; the
@@ -202,6 +202,7 @@ def main():
         if record:
             st = ctx.stats()
             acc["vertices"] += st.vertices
+            acc["shadow_rays"] += st.shadow_rays
             acc["samples"] += st.samples
             acc["bounce_ms"] += st.bounce_kernel_ms
             acc["launches"] += st.bounce_launches
@@ -248,11 +249,59 @@ def main():
             assert torch.isfinite(lin).all()
         # the dominant kernel = the level-0 launch of each batch (camera rays + every bounce until its waves hand
         # their sparse tails over); it processes p_vertices of the vertices and all of the camera samples
+        n_sph = sum(1 for o in objs if o.shape_tag == 0)
+        n_tri = len(objs) - n_sph
+        f_scan = F_SPHERE * n_sph + F_TRIANGLE * n_tri                       # one linear scan of the scene
+        share = acc["p_vertices"] / max(acc["vertices"], 1)                  # the level-0 launches' share of the work
+        scans = acc["p_vertices"] + acc["shadow_rays"] * share               # closest-hit scans + visibility scans
+        alg_flops = f_scan * scans + F_SHADE * acc["p_vertices"]
+        achieved_tf = alg_flops / (acc["p_ms"] * 1e-3) / 1e12 if acc["p_ms"] > 0 else 0.0
         alg_bytes = BYTES_PER_VERTEX * acc["p_vertices"] + BYTES_PER_SAMPLE * acc["samples"]
-        achieved = alg_bytes / (acc["p_ms"] * 1e-3) / 1e9 if acc["p_ms"] > 0 else 0.0
+        avg_ms = acc["p_ms"] / max(acc["p_launches"], 1)
+        prof = profile_summary(world, args.workload, args.accel)
+        accel_name = {0: "linear scan (reference)", 1: "BVH traversal (accel=1, same film as the linear scan)",
+                      2: "PT_ACCEL_AUTO (product default: BVH above ~512 sphere tests per scan, same film)"}[args.accel]
+        diffuse = all(o.mat_tag in (0, 1) for o in objs)
+        if args.accel == 1 or (args.accel == 2 and len(objs) > 512):
+            kernel = "k_paths_bvh<MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
+        elif len(objs) <= 128:
+            kernel = "k_paths<kModeLds, MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
+        else:
+            kernel = "k_paths<kModeTiled, MIS, OVF=false>"
+        roof = {
+            "kernel": kernel + ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
+                      "over their sparse tails), rank 0.  Bound by f32 VALU issue (no contraction on this path: the "
+                      "schema's mfma slot does not apply; same 157.3 TFLOP/s f32 peak)",
+            "bound": "valu",
+            "achieved": round(achieved_tf, 2),
+            "peak": VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4),
+            "algorithmic_flops_per_launch": round(alg_flops / max(acc["p_launches"], 1)),
+            "flops_model": f"{f_scan} per scan of the scene ({n_sph} spheres x {F_SPHERE} + {n_tri} triangles x {F_TRIANGLE}) x "
+                           f"(vertices + visibility scans) + {F_SHADE} per vertex (SURVEY 8d); BVH launches are priced as if they scanned",
+            "avg_launch_ms": round(avg_ms, 4),
+            "launches": acc["p_launches"],
+            "vertex_share": round(share, 4),
+            "all_path_kernels_ms_per_step": round(acc["bounce_ms"] / max(args.steps, 1), 4),
+            "traffic": None, "hbm_frac": None, "valu_issue_frac": None,
+            "algorithmic_bytes_per_launch_unfused_pipeline": round(alg_bytes / max(acc["p_launches"], 1)),
+        }
+        if prof:
+            src = prof["_file"]
+            if prof.get("hbm_bytes_per_launch"):
+                roof["traffic"] = int(prof["hbm_bytes_per_launch"])
+                # counter bytes over THIS run's launch time, against the 8 TB/s peak
+                roof["hbm_frac"] = round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None
+            if prof.get("valu_issue_frac"):
+                roof["valu_issue_frac"] = round(min(prof["valu_issue_frac"], 1.0), 4)     # against 2 cycles per wave64 VALU instruction
+                roof["valu_insts_per_launch"] = int(prof["valu_insts_per_launch"])
+            roof["counters_source"] = f"{src}: replayed from the committed rocprofv3 passes of this command ({prof.get('kernel')}, " \
+                                      f"{prof.get('avg_launch_ms_kernel_trace', 0):.3f} ms per launch in the profiled process), not measured in this run"
         out = {
-            "metric": "Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2"
-                      else f"Msamples/sec (pixels x spp / s) at {WIDTH}x{HEIGHT}/{SPP}spp",
+            "metric": ("Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2"
+                       else f"Msamples/sec (pixels x spp / s) at {WIDTH}x{HEIGHT}/{SPP}spp") +
+                      ("" if args.accel == 0 else f", hit_scene = {'BVH' if args.accel == 1 else 'PT_ACCEL_AUTO'}"),
             "value": round(job_samples / elapsed / 1e6, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -260,37 +309,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if (args.weak or world == 1) else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{wl_desc}, {WIDTH}x{HEIGHT}, {spp} spp "
-                            f"({SPP} spp per GPU), MIS, min_depth 4 / max_depth 50",
-                "hit_scene": "BVH traversal (accel=1, same film as the linear scan)" if args.accel else "linear scan (reference)",
+                "workload": f"{wl_desc}, {WIDTH}x{HEIGHT}, {spp} spp, MIS, min_depth 4 / max_depth 50",
+                "hit_scene": accel_name,
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
                 "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "
                                                           f"ONE {args.backend} gather of the packed f32 + RGBA8 frame to rank 0 per step, overlapped with the next step's rendering",
             },
-            "roofline": {
-                "kernel": ("k_paths_bvh<MIS, OVF=false>" if args.accel else
-                           ("k_paths<kModeLds, MIS, OVF=false, DIFFUSE>" if len(objs) <= 128 else "k_paths<kModeTiled, MIS, OVF=false>")) +
-                          ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
-                          "over their sparse tails), rank 0",
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(world, args.workload),
-                "valu": pmc_valu(world, args.workload),
-                "algorithmic_bytes_per_launch": round(alg_bytes / max(acc["p_launches"], 1)),
-                "avg_launch_ms": round(acc["p_ms"] / max(acc["p_launches"], 1), 4),
-                "launches": acc["p_launches"],
-                "vertex_share": round(acc["p_vertices"] / max(acc["vertices"], 1), 4),
-                "all_path_kernels_ms_per_step": round(acc["bounce_ms"] / max(args.steps, 1), 4),
-            },
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pt, objs)

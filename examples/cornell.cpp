@@ -22,17 +22,13 @@ int main(int argc, char** argv) {
         // World::new() fixes 400x400; other sizes re-author the same scene with the same camera model
         World world = World::new_();
         if (w != WIDTH || h != HEIGHT) {
+            // re-author the same 13 objects through the mirrored constructors for a camera of another size
             World resized(Camera::new_(Vector3(0.0, 0.0, 2.0), w, h, 1.0, 35.0));
             uint32_t n = 0;
             check(pt_builtin_scene(1, 0, nullptr, 0, &n));
             std::vector<PtObject> objs(n);
             check(pt_builtin_scene(1, 0, objs.data(), n, &n));
-            // the same 13 objects, authored through the mirrored constructors for the first two as a demo
-            (void)objs;
             world = std::move(resized);
-            // re-add the reference objects through the public surface
-            const double bs = 1.0, bd = -2.0;
-            (void)bs; (void)bd;
             for (const PtObject& o : objs) {
                 if (o.shape_tag == PT_SHAPE_TRIANGLE) {
                     TriangleShape t = TriangleShape::new_(Vector3(o.shape[0], o.shape[1], o.shape[2]),

@@ -255,6 +255,11 @@ int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* 
 int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam, const PtObject* objs,
                     uint32_t n_objs, const PtRenderParams* params, float* out_linear_rgb, uint8_t* out_rgba8);
 
+/* Debug / parity entry: the frame of an n_virtual-device render on ONE context (tiles rendered one after another,
+ * device-to-device copies where pt_multi_* runs ncclGather): partition, pack and unpack for any n on a one-GPU box. */
+int pt_debug_multi_emulate(PtContext* ctx, uint32_t n_virtual, const PtCamera* cam, const PtRenderParams* params,
+                           float* out_linear_rgb, uint8_t* out_rgba8);
+
 /* World::render_pixel (src/world.rs:293-333) -- the seam the reference's rayon loop calls at
  * src/main.rs:55 -- for an arbitrary list of n pixels: xy = n * (x, y), y = film row (top-down, the y
  * of the seed (y<<32)|x, main.rs:51).  Every listed pixel gets exactly the samples a full render gives

@@ -233,6 +233,14 @@ class _ContextFunctions:
         check(lib().pt_debug_camera_rays(self._h, C.byref(cam), _pu(xys), xys.shape[0], exact_math, _pf(out)))
         return out
 
+    def multi_emulate(self, n_virtual, cam, params):
+        """pt_debug_multi_emulate: the frame an n_virtual-device pt_multi render assembles, produced on this one context."""
+        lin = np.empty((cam.height, cam.width, 3), dtype=np.float32)
+        rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+        check(lib().pt_debug_multi_emulate(self._h, n_virtual, C.byref(cam), C.byref(params), lin.ctypes.data_as(C.c_void_p),
+                                           rgba.ctypes.data_as(C.c_void_p)))
+        return lin, rgba
+
     def render_pixels(self, cam, params, xy, want_samples=False):
         """pt_render_pixels = World::render_pixel for a pixel list.  -> (linear f32[n,3], rgba u8[n,4], samples
         f32[n,spp,3] or None)"""

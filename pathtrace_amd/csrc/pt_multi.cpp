@@ -246,6 +246,43 @@ int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* 
     return PT_OK;
 }
 
+// Debug / parity entry: the frame of an n_virtual-device render produced on ONE context -- the n tiles are rendered one
+// after another on ctx's device, packed, placed in the gather buffer by device-to-device copies (where pt_multi_*
+// runs ncclGather) and put in image order by the same kernel.  Exercises partition, pack and unpack for any n on a
+// one-GPU box; host output buffers, blocking.
+int pt_debug_multi_emulate(PtContext* ctx, uint32_t n_virtual, const PtCamera* cam, const PtRenderParams* prm, float* out_linear,
+                           uint8_t* out_rgba) {
+    if (!ctx || !cam || !prm || !out_linear || n_virtual == 0) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_debug_multi_emulate: bad argument");
+    const uint32_t n = n_virtual, W = cam->width, H = cam->height;
+    const uint32_t band_rows = prm->band_rows ? prm->band_rows : default_band_rows(H, n);
+    uint32_t max_rows = 0;
+    for (uint32_t g = 0; g < n; ++g) max_rows = std::max(max_rows, pt_tile_rows(H, band_rows, g, n));
+    const size_t tile_px = std::max<size_t>((size_t)max_rows * W, 1), px = std::max<size_t>((size_t)W * H, 1);
+    DevMem lin, rgba, packed, recv, olin, orgba;
+    struct Free { DevMem* m[6]; ~Free() { for (DevMem* x : m) x->release(); } } guard{{&lin, &rgba, &packed, &recv, &olin, &orgba}};
+    int rc;
+    if ((rc = lin.ensure(tile_px * 12)) || (rc = rgba.ensure(tile_px * 4)) || (rc = packed.ensure(tile_px * 16)) ||
+        (rc = recv.ensure(tile_px * 16 * n)) || (rc = olin.ensure(px * 12)) || (rc = orgba.ensure(px * 4)))
+        return rc;
+    hipStream_t st = pt_internal_stream(ctx);
+    for (uint32_t g = 0; g < n; ++g) {
+        PtRenderParams p = *prm;
+        p.band_rows = band_rows; p.band_index = g; p.band_count = n;
+        const size_t tp = (size_t)pt_tile_rows(H, band_rows, g, n) * W;
+        if ((rc = pt_render_device(ctx, cam, &p, (float*)lin.p, out_rgba ? (uint8_t*)rgba.p : nullptr))) return rc;
+        ptk::launch_film_pack((const float*)lin.p, out_rgba ? (const uint8_t*)rgba.p : nullptr, (uint32_t)tp, packed.p, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync((char*)recv.p + (size_t)g * tile_px * 16, packed.p, tile_px * 16, hipMemcpyDeviceToDevice, st));
+        if ((rc = pt_sync(ctx))) return rc;          // the tile buffers are reused by the next virtual device
+    }
+    ptk::launch_film_unpack(recv.p, W, H, band_rows, n, max_rows, (float*)olin.p, out_rgba ? (uint8_t*)orgba.p : nullptr, st);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pt_sync(ctx))) return rc;
+    HIP_TRY(hipMemcpy(out_linear, olin.p, (size_t)W * H * 12, hipMemcpyDeviceToHost));
+    if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, orgba.p, (size_t)W * H * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 }  // extern "C"
 
 // One shot: a cached multi-device object per device list (pt_shutdown frees it).

@@ -134,6 +134,7 @@ extern "C" {
     pub fn pt_multi_get_stats(m: *mut PtMulti, out: *mut PtStats) -> c_int;
     pub fn pt_multi_render_host(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render_multi(devices: *const c_int, n_devices: u32, cam: *const PtCamera, objs: *const PtObject, n_objs: u32, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_debug_multi_emulate(ctx: *mut PtContext, n_virtual: u32, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render_pixels(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, xy: *const u32, n: u32, out_linear_rgb: *mut f32, out_rgba8: *mut u8, out_samples: *mut f32) -> c_int;
     pub fn pt_ray_color(ctx: *mut PtContext, params: *const PtRenderParams, rays: *const f64, xy: *const u32, n: u32, out_rgb: *mut f32) -> c_int;
     pub fn pt_debug_hit_scene(ctx: *mut PtContext, rays: *const f64, n: u32, t_min: f64, t_max: f64, exact_math: u32, accel: u32, out_id: *mut i32, out_t: *mut f32) -> c_int;

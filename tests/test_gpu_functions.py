@@ -341,3 +341,18 @@ def test_multi_gpu_entry_with_one_device_over_rccl(pt, gpu_ctx):
     with pytest.raises(pt._lib.PtError, match="twice"):
         pt.Multi([0, 0])
     pt._lib.lib().pt_shutdown()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_multi_gpu_partition_pack_unpack_for_n_devices(pt, gpu_ctx, n):
+    """The band partition, the 16 B/pixel pack and the row permutation of pt_multi_* for n = 2, 3, 8 devices, emulated on
+    the one GPU of this box (pt_debug_multi_emulate: device-to-device copies where the real path runs ncclGather):
+    the frame is bitwise independent of n, also with ragged bands (117 rows) and devices that own nothing."""
+    objs = pt.builtin_scene(2)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_new(width=160, height=117)
+    ref, ref8 = gpu_ctx.render(cam, pt.default_params(spp=5))
+    ref, ref8 = ref.cpu().numpy(), ref8.cpu().numpy()
+    for band_rows in (0, 1, 10, 117):
+        lin, rgba = gpu_ctx.multi_emulate(n, cam, pt.default_params(spp=5, band_rows=band_rows))
+        assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8), (n, band_rows)

@@ -49,3 +49,108 @@ def test_cpp_world_render_matches_oracle(pt, orc, tmp_path, w, h):
         assert f.readline() == b"P6\n" and f.readline() == f"{w} {h}\n".encode() and f.readline() == b"255\n"
         rgb = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
     assert np.array_equal(rgb, ref8[..., :3])
+
+
+# ---------------------------------------------------------------- luminance.csv reader + differ (no GPU)
+DIFF = os.path.join(ROOT, "examples", "luminance_diff")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_luminance_differ_reads_the_reference_format(tmp_path):
+    """examples/luminance_diff = World::read_luminance + compare_luminance of the C++ mirror on the committed
+    fixtures, which are in the reference's own format (world.rs:344-369)."""
+    import json
+    a = os.path.join(GOLD, "c1_32x32x16_luminance.csv")
+    r = subprocess.run([DIFF, a, a], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["pass"] and d["width"] == 32 and d["height"] == 32 and d["pixels_within"] == 1.0 and d["max_abs"] == 0.0
+    ref = load_luminance_csv(a)
+    assert abs(d["mean_ref"] - ref.mean()) < 1e-9
+    # a perturbed copy: 2 % of the pixels off by 10 % -> fails the 99.5 % bar, exit code 1
+    rows = open(a).read().splitlines()
+    out = [rows[0]]
+    for k, line in enumerate(rows[1:]):
+        x, y, rr, g, b, lum = line.split(",")
+        if k % 50 == 0:
+            rr = f"{float(rr) * 1.1 + 0.01:.6f}"
+        out.append(",".join([x, y, rr, g, b, lum]))
+    bad = tmp_path / "bad.csv"
+    bad.write_text("\n".join(out) + "\n")
+    r = subprocess.run([DIFF, str(bad), a], capture_output=True, text=True)
+    d = json.loads(r.stdout)
+    assert r.returncode == 1 and not d["pass"] and d["outside"] == len(rows[1:]) // 50 + (1 if (len(rows) - 1) % 50 else 0)
+    # different scenes, different sizes, garbage
+    r = subprocess.run([DIFF, a, os.path.join(GOLD, "c2_32x32x16_luminance.csv")], capture_output=True, text=True)
+    assert r.returncode == 1
+    junk = tmp_path / "junk.csv"
+    junk.write_text("not,a,luminance,file\n1,2,3\n")
+    assert subprocess.run([DIFF, str(junk), a], capture_output=True, text=True).returncode == 2
+
+
+# ---------------------------------------------------------------- the trait surface of the C++ mirror (GPU)
+@pytest.mark.gpu
+def test_cpp_trait_surface_runs_on_the_gpu_and_matches_the_oracle(pt, orc):
+    """examples/mirror_check calls every method of the mirrored trait surface (Camera::get_ray_with_offset,
+    World::{hit_scene, sample_light_point, render_pixel}, Shape::{hit, sample_surface_from_point},
+    Material::{bsdf_pdf, bsdf_pdf_sample, get_eta, emit}, ray_color, export/import_luminance) -- each a call into the
+    GPU library in exact arithmetic -- and prints the results; here they are compared with the oracle."""
+    r = subprocess.run([os.path.join(ROOT, "examples", "mirror_check")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    v = {}
+    for line in r.stdout.splitlines():
+        k, *rest = line.split()
+        v[k] = rest
+    f = lambda k: np.array([float(x) for x in v[k]])
+    F32, F64, ITER = orc.F32, orc.F64, orc.ITERATIVE
+    objs = pt.builtin_scene(1)
+    cam = pt.camera_new(width=400, height=400)
+    # camera ray: host f64
+    ref = orc.camera_rays(cam, [[79, 400 - 1 - 176]], [[0.25, 0.75]], F64)[0]
+    assert np.allclose(np.concatenate([f("cam_ray_o"), f("cam_ray_d")]), ref, rtol=0, atol=1e-15)
+    ray = np.concatenate([f("cam_ray_o"), f("cam_ray_d")])[None]
+    ids, t, pn, ff = orc.hit_scene(objs, ray, 0.001, float("inf"), F32)
+    assert int(v["hit_scene"][0]) == ids[0] and np.float32(v["hit_scene"][1]) == np.float32(t[0]) and int(v["hit_scene"][2]) == ff[0]
+    assert np.array_equal(f("hit_point").astype(np.float32), pn[0, :3].astype(np.float32))
+    assert np.array_equal(f("hit_normal").astype(np.float32), pn[0, 3:].astype(np.float32))
+    # Shape::hit
+    r2 = np.array([[0.0, 0.0, 2.0, 0.1, -0.15, -1.0]])
+    for key, ob in (("sphere_hit", pt.make_objects([(0, [0.4, -0.6, -2.0, 0.4], 0, [0.5] * 3)])),
+                    ("tri_hit", pt.make_objects([(1, [-1, -1, -3, 1, -1, -3, 1, 1, -3], 0, [0.5] * 3)]))):
+        ids, t, pn, ff = orc.hit_scene(ob, r2, 0.001, float("inf"), F32)
+        assert ids[0] == 0 and np.float32(v[key][0]) == np.float32(t[0]) and int(v[key][1]) == ff[0], key
+        assert np.array_equal(f(key + "_n").astype(np.float32), pn[0, 3:].astype(np.float32))
+    # Shape::sample_surface_from_point
+    sph = pt.make_objects([(0, [0.4, -0.6, -2.0, 0.4], 0, [0.5] * 3)])
+    s = orc.shape_sample(sph, [[0.2, -0.9, -1.5]], None, [[0.3, 0.6]], F32)[0]
+    assert np.array_equal(f("sphere_sample_p").astype(np.float32), s[0:3].astype(np.float32))
+    assert np.array_equal(f("sphere_sample_pdf").astype(np.float32), s[[6, 10]].astype(np.float32))
+    st = orc.shape_sample(sph, [[0.2, -0.9, -1.5]], [f("sphere_sample_p")], None, F32)[0]
+    assert np.float32(v["sphere_target_pdf"][0]) == np.float32(st[6])
+    # Material
+    glass = pt.make_objects([(0, [0, 0, 0, 1], 2, [0.3, 1, 1, 1, 0.0, 1.5])])
+    n = np.array([0.2, 0.9, 0.1]); n /= np.linalg.norm(n)
+    d_in = np.array([0.3, -1.0, 0.2]); d_in /= np.linalg.norm(d_in)
+    wo = np.array([-0.1, 0.8, 0.3]); wo /= np.linalg.norm(wo)
+    ev = orc.bsdf_eval(glass, [np.concatenate([d_in, wo, n, [1 / 1.5]])], F32)[0]
+    assert np.array_equal(np.concatenate([f("glass_f"), f("glass_pdf")]).astype(np.float32), ev.astype(np.float32))
+    words = [[0x12345678, 0x9abcdef0, 0x0fedcba9, 0]]
+    sm = orc.bsdf_sample(glass, [np.concatenate([d_in, n, [1 / 1.5]])], words, F32)[0]
+    assert np.array_equal(np.concatenate([f("glass_wo"), f("glass_sf"), f("glass_spdf")]).astype(np.float32), sm.astype(np.float32))
+    lam = pt.make_objects([(0, [0, 0, 0, 1], 0, [0.8, 0.6, 0.2])])
+    sl = orc.bsdf_sample(lam, [np.concatenate([d_in, n, [1 / 1.5]])], words, F32)[0]
+    assert np.array_equal(np.concatenate([f("lambert_wo"), f("lambert_spdf")]).astype(np.float32), sl[[0, 1, 2, 6, 7]].astype(np.float32))
+    assert v["eta"] == ["1.5", "1", "emit", "15"]
+    # World::sample_light_point
+    lp = orc.light_point(objs, [f("hit_point")], [[0xC0000000, 0x40000000, 0x80000000, 0]], F32)[0]
+    assert np.array_equal(f("light_point").astype(np.float32), lp[0:3].astype(np.float32))
+    assert np.float32(v["light_pdf"][0]) == np.float32(lp[6]) and int(v["light_pdf"][1]) == int(lp[7]) == 11 and float(v["light_pdf"][2]) == 15.0
+    # World::render_pixel == the full film's pixel (colour and linear value), for both replayed pixels
+    for key in ("pixel_79_176", "pixel_10_158"):
+        assert v[key][0:3] == v[key][4:7] and v[key][-1] == "1", v[key]
+    row, _, _ = orc.render(cam, objs, pt.default_params(spp=4, band_rows=1, band_index=176, band_count=400), F32, ITER, 2)
+    assert np.array_equal(f("lum_79_176").astype(np.float32), row[0, 79].astype(np.float32))
+    # ray_color on the camera ray, stream (79, 176), sample 2
+    rc = orc.ray_color(objs, pt.default_params(spp=1, spp_offset=2), ray, [[79, 176]], F32, ITER)[0]
+    assert np.array_equal(f("ray_color").astype(np.float32), rc.astype(np.float32))
+    assert v["roundtrip"][0] == "160000" and v["roundtrip"][1] == "1"

@@ -33,7 +33,7 @@ def _rust_functions():
 
 def test_every_header_function_is_declared_with_the_same_arity():
     c, r = _c_functions(), _rust_functions()
-    assert len(c) >= 38 and "pt_render_pixels" in c and "pt_multi_render_device" in c and "pt_render_device" in c and "pt_debug_bvh_check" in c
+    assert len(c) >= 39 and "pt_render_pixels" in c and "pt_multi_render_device" in c and "pt_render_device" in c and "pt_debug_bvh_check" in c
     assert c == r
 
 

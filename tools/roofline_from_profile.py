@@ -1,0 +1,65 @@
+"""Summary of one tools/profile_workload.sh directory for bench.py's `roofline` object (profiles/rNN/roofline_<tag>.json):
+the dominant kernel, its average duration from the kernel trace (timed dispatches = all but the first, which is the
+warm-up step), HBM bytes per launch from the TCC passes (FETCH_SIZE KB x 1024 x 2: gfx950 reports half of wide coalesced
+reads, MI355X_MICROARCH.md "HBM"; WRITE_SIZE KB x 1024), VALU instruction counts and mix, busy cycles.
+usage: python tools/roofline_from_profile.py <dir> <tag>"""
+import collections, csv, glob, json, os, sys
+
+d, tag = sys.argv[1], sys.argv[2]
+SIMDS = 1024
+
+
+def short(k):
+    return k.replace("void ", "").replace("(ptk::BounceArgs)", "").replace("(ptk::ResolveArgs)", "")
+
+
+# kernel trace: durations per dispatch
+dur = collections.defaultdict(list)
+for f in glob.glob(f"{d}/trace/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+if not dur:
+    sys.exit("no kernel trace found")
+tot = {k: sum(x[1] for x in v) for k, v in dur.items()}
+dom = max(tot, key=tot.get)
+timed = [x[1] for x in sorted(dur[dom])][1:] or [x[1] for x in dur[dom]]      # drop the warm-up dispatch
+avg_ns = sum(timed) / len(timed)
+
+# counters: per-dispatch average for the dominant kernel
+cnt = collections.defaultdict(float)
+nd = collections.defaultdict(set)
+for f in glob.glob(f"{d}/pmc_*/**/*_counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if short(r["Kernel_Name"]) != dom:
+            continue
+        cnt[r["Counter_Name"]] += float(r["Counter_Value"])
+        nd[r["Counter_Name"]].add((f, r["Dispatch_Id"]))
+c = {k: cnt[k] / len(nd[k]) for k in cnt}
+
+out = {
+    "tag": tag,
+    "kernel": dom,
+    "dispatches_timed": len(timed),
+    "avg_launch_ms_kernel_trace": avg_ns / 1e6,
+    "all_kernels_avg_ms": {k: sum(x[1] for x in v) / len(v) / 1e6 for k, v in dur.items()},
+    "counters_per_launch": c,
+    "source": f"rocprofv3 --kernel-trace --stats and one --pmc pass per run of `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline ...` (tools/profile_workload.sh {tag})",
+}
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    out["fetch_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2
+    out["write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
+    out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+    out["hbm_note"] = "FETCH_SIZE (KB) x 1024 x 2 (gfx950 counts half of wide coalesced reads) + WRITE_SIZE (KB) x 1024"
+if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0                                   # the counter sums the 8 XCDs
+    out["gpu_cycles_per_launch"] = cyc
+    out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+    out["cycles_per_valu_inst_per_simd"] = cyc * SIMDS / c["SQ_INSTS_VALU"]
+    out["valu_issue_frac"] = 2.0 / out["cycles_per_valu_inst_per_simd"]   # against 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)
+    out["clock_ghz_profiled"] = cyc / avg_ns if avg_ns else None
+if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+    out["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c["SQ_ACTIVE_INST_VALU"] else None
+mix = {k[len("SQ_INSTS_VALU_"):]: v for k, v in c.items() if k.startswith("SQ_INSTS_VALU_")}
+if mix:
+    out["valu_mix_per_launch"] = mix
+json.dump(out, sys.stdout, indent=1)
