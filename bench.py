@@ -279,7 +279,7 @@ def main():
             "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4),
             "algorithmic_flops_per_launch": round(alg_flops / max(acc["p_launches"], 1)),
             "flops_model": f"{f_scan} per scan of the scene ({n_sph} spheres x {F_SPHERE} + {n_tri} triangles x {F_TRIANGLE}) x "
-                           f"(vertices + visibility scans) + {F_SHADE} per vertex (SURVEY 8d); BVH launches are priced as if they scanned",
+                           f"(vertices + visibility scans) + {F_SHADE} per vertex (SURVEY 8d)",
             "avg_launch_ms": round(avg_ms, 4),
             "launches": acc["p_launches"],
             "vertex_share": round(share, 4),
@@ -287,6 +287,18 @@ def main():
             "traffic": None, "hbm_frac": None, "valu_issue_frac": None,
             "algorithmic_bytes_per_launch_unfused_pipeline": round(alg_bytes / max(acc["p_launches"], 1)),
         }
+        bvh_run = args.accel == 1 or (args.accel == 2 and len(objs) > 512)
+        if bvh_run:
+            # a BVH traversal has no closed-form algorithmic flop count (the scan model would price work it never does
+            # and give a "fraction" above 1): price it with the f32 flops it EXECUTED per the counter pass, if there is one
+            roof["achieved"] = roof["frac"] = None
+            roof["algorithmic_flops_per_launch"] = None
+            roof["flops_model"] = "executed f32 flops of the launch from the rocprofv3 counter pass (SQ_INSTS_VALU_FLOPS_FP32 x 64 lanes x lane utilisation)"
+            cp = (prof or {}).get("counters_per_launch", {})
+            if cp.get("SQ_INSTS_VALU_FLOPS_FP32") and prof.get("lane_utilisation") and avg_ms > 0:
+                ex = cp["SQ_INSTS_VALU_FLOPS_FP32"] * 64.0 * prof["lane_utilisation"]
+                roof["achieved"] = round(ex / (avg_ms * 1e-3) / 1e12, 2)
+                roof["frac"] = round(roof["achieved"] / VALU_PEAK_TFLOPS, 4)
         if prof:
             src = prof["_file"]
             if prof.get("hbm_bytes_per_launch"):

@@ -504,9 +504,11 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
 #define PT_BOUNCE_WAVES_TILED 5
 #endif
 // film position of a path -> its pixel: the RNG key (x, y) and camera pixel.  LIST: looked up in the pixel list.
+// A lane without a path may carry stale slot contents as its film position (k_paths reads whole chunks): it must not
+// index the list with them.
 template <bool LIST>
-PT_DEV void pixel_key(const BounceArgs& a, const PathState& p, uint32_t& kx, uint32_t& py) {
-    if (LIST) { const uint2 k = a.pixels[(p.yl << 16) | p.px]; kx = k.x; py = k.y; }
+PT_DEV void pixel_key(const BounceArgs& a, const PathState& p, bool active, uint32_t& kx, uint32_t& py) {
+    if (LIST) { const uint2 k = a.pixels[active ? ((p.yl << 16) | p.px) : 0u]; kx = k.x; py = k.y; }
     else { kx = p.px; py = image_row(a.tile, p.yl); }
 }
 // a continuation launch whose path count is only known on the device: count, chunks and segment size from there
@@ -584,7 +586,7 @@ k_paths(BounceArgs a) {
             if (!active) { p.o = parked_origin(); p.d = parked_dir(); }
         }
         uint32_t kx, py;                                  // key of the path's RNG stream = (x, y), main.rs:51
-        pixel_key<LIST>(a, p, kx, py);
+        pixel_key<LIST>(a, p, active, kx, py);
         const uint32_t sample = a.s_base + p.s_local;
 
         if (first && !from_overflow && active) camera_ray(a.cam, sample, kx, py, p.o, p.d);
@@ -879,7 +881,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 divmod_magic(pid, a.np, a.np_magic, p.s_local, pix);
                 divmod_magic(pix, W, a.film_w_magic, p.yl, p.px);
                 uint32_t kx, py;
-                pixel_key<LIST>(a, p, kx, py);
+                pixel_key<LIST>(a, p, active, kx, py);
                 camera_ray(a.cam, a.s_base + p.s_local, kx, py, p.o, p.d);
             }
             store_state(q, it * 64u + lane, p);     // dense: only the last chunk of the batch can be partial
@@ -903,7 +905,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
                 if (active) { unpack_ray(p, q.q[0][s], q.q[1][s]); h = aux[s]; }
                 Vertex v;
                 uint32_t kx, py;
-                pixel_key<LIST>(a, p, kx, py);
+                pixel_key<LIST>(a, p, active, kx, py);
                 vertex_begin<true, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, a.s_base + p.s_local, kx, py, v);
                 if (active) {
                     sr0[s] = make_float4(v.hit.point.x, v.hit.point.y, v.hit.point.z, v.light_dir.x);
@@ -925,7 +927,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             float4 h = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
             if (active) { p = unpack_state(q.q[0][s], q.q[1][s], q.q[2][s], q.q[3][s]); h = aux[s]; }
             uint32_t kx, py;
-            pixel_key<LIST>(a, p, kx, py);
+            pixel_key<LIST>(a, p, active, kx, py);
             const uint32_t sample = a.s_base + p.s_local;
             wave_vertices += (uint32_t)__popcll(__ballot(active));
             if (!OVF) {

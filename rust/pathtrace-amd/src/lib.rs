@@ -116,6 +116,71 @@ impl Renderer {
         check(unsafe { sys::pt_get_stats(self.ctx, &mut s) })?;
         Ok(s)
     }
+    /// `World::render_pixel` (`world.rs:293-333`) for a pixel list: every listed pixel gets exactly the samples a
+    /// full render gives it.  `want_samples`: also the radiance of every camera sample, `[pixel][sample][rgb]`
+    /// (= `ray_color`'s return values, what the reference's diagnostics print, `world.rs:378-417`).
+    pub fn render_pixels(&mut self, cam: &Camera, params: &RenderParams, pixels: &[(u32, u32)], want_samples: bool) -> Result<PixelFilm, Error> {
+        let n = pixels.len();
+        let xy: Vec<u32> = pixels.iter().flat_map(|&(x, y)| [x, y]).collect();
+        let mut out = PixelFilm {
+            linear_rgb: vec![0f32; n * 3],
+            rgba8: vec![0u8; n * 4],
+            samples: if want_samples { vec![0f32; n * params.spp as usize * 3] } else { Vec::new() },
+        };
+        let smp = if want_samples { out.samples.as_mut_ptr() } else { std::ptr::null_mut() };
+        check(unsafe { sys::pt_render_pixels(self.ctx, cam, params, xy.as_ptr(), n as u32, out.linear_rgb.as_mut_ptr(), out.rgba8.as_mut_ptr(), smp) })?;
+        Ok(out)
+    }
+    /// `RenderingStrategy::ray_color(world, ray, 0, rng, Vector3::one())` (`rendering.rs:34-142`, `214-265`) for
+    /// arbitrary rays (origin, direction), the rng of ray i being the stream of key `keys[i]` at sample
+    /// `params.spp_offset`.  Returns RGB per ray.
+    pub fn ray_color(&mut self, params: &RenderParams, rays: &[([f64; 3], [f64; 3])], keys: &[(u32, u32)]) -> Result<Vec<[f32; 3]>, Error> {
+        assert_eq!(rays.len(), keys.len());
+        let r6: Vec<f64> = rays.iter().flat_map(|(o, d)| [o[0], o[1], o[2], d[0], d[1], d[2]]).collect();
+        let xy: Vec<u32> = keys.iter().flat_map(|&(x, y)| [x, y]).collect();
+        let mut out = vec![0f32; rays.len() * 3];
+        check(unsafe { sys::pt_ray_color(self.ctx, params, r6.as_ptr(), xy.as_ptr(), rays.len() as u32, out.as_mut_ptr()) })?;
+        Ok(out.chunks_exact(3).map(|c| [c[0], c[1], c[2]]).collect())
+    }
+}
+
+/// Result of `Renderer::render_pixels`.
+pub struct PixelFilm {
+    pub linear_rgb: Vec<f32>,
+    pub rgba8: Vec<u8>,
+    /// `[pixel][sample][rgb]`, empty unless requested
+    pub samples: Vec<f32>,
+}
+
+/// Several GPUs of one node in ONE process (`pt_multi_*`): interleaved row bands, one RCCL gather of the film to
+/// the first device.  The frame does not depend on the number of devices.
+pub struct Multi {
+    m: *mut sys::PtMulti,
+}
+unsafe impl Send for Multi {}
+
+impl Multi {
+    pub fn new(devices: &[i32]) -> Result<Self, Error> {
+        let mut m = std::ptr::null_mut();
+        check(unsafe { sys::pt_multi_create(devices.as_ptr(), devices.len() as u32, &mut m) })?;
+        Ok(Multi { m })
+    }
+    pub fn upload(&mut self, objects: &[Object]) -> Result<(), Error> {
+        check(unsafe { sys::pt_multi_scene_upload(self.m, objects.as_ptr(), objects.len() as u32) })
+    }
+    /// The whole frame (band_* of `params` are ignored: the object owns the partition); blocking.
+    pub fn render(&mut self, cam: &Camera, params: &RenderParams) -> Result<Film, Error> {
+        let n = cam.width as usize * cam.height as usize;
+        let mut film = Film { width: cam.width, rows: cam.height, linear_rgb: vec![0f32; n * 3], rgba8: vec![0u8; n * 4] };
+        check(unsafe { sys::pt_multi_render_host(self.m, cam, params, film.linear_rgb.as_mut_ptr(), film.rgba8.as_mut_ptr()) })?;
+        Ok(film)
+    }
+}
+
+impl Drop for Multi {
+    fn drop(&mut self) {
+        unsafe { sys::pt_multi_destroy(self.m) };
+    }
 }
 
 impl Drop for Renderer {

@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo processes each produce their interleaved row
+"""N>1 path on CPU: world_size-2/3/4 gloo processes each produce their interleaved row
 bands (the oracle stands in for the GPU renderer here) and rank 0 gathers the
 frame with pathtrace_amd.dist.gather_tiles -- the same code path bench.py runs
 over RCCL.  The assembled frame must equal the single-process render bit for bit."""
@@ -67,11 +67,13 @@ def _worker(rank, world, port, H, W, band_rows, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H,band_rows", [(22, 4), (16, 16), (9, 1)])
-def test_two_ranks_gather_equals_single_render(pt, orc, tmp_path, H, band_rows):
+@pytest.mark.parametrize("world,H,band_rows", [(2, 22, 4), (2, 16, 16), (2, 9, 1), (3, 23, 3), (4, 21, 2), (4, 5, 4)])
+def test_ranks_gather_equals_single_render(pt, orc, tmp_path, world, H, band_rows):
+    """world_size 2, 3 and 4 with ragged bands (the last band short, ranks that own fewer bands than others or
+    nothing at all): the gathered frame equals the single-rank film bit for bit."""
     W = 20
     out = str(tmp_path / "frame.npz")
-    mp.spawn(_worker, args=(2, _free_port(), H, W, band_rows, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), H, W, band_rows, out), nprocs=world, join=True)
     got = np.load(out)
     cam = pt.camera_new(width=W, height=H)
     full, full8, _ = orc.render(cam, pt.builtin_scene(1), pt.default_params(spp=2), orc.F32, orc.ITERATIVE)

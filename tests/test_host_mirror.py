@@ -107,14 +107,15 @@ def test_cpp_trait_surface_runs_on_the_gpu_and_matches_the_oracle(pt, orc):
     cam = pt.camera_new(width=400, height=400)
     # camera ray: host f64
     ref = orc.camera_rays(cam, [[79, 400 - 1 - 176]], [[0.25, 0.75]], F64)[0]
-    assert np.allclose(np.concatenate([f("cam_ray_o"), f("cam_ray_d")]), ref, rtol=0, atol=1e-15)
-    ray = np.concatenate([f("cam_ray_o"), f("cam_ray_d")])[None]
+    assert np.allclose(np.concatenate([f("cam_ray_o"), f("cam_ray_d")]), ref, rtol=0, atol=2e-9)       # printed with 9 digits
+    ray = ref[None]
     ids, t, pn, ff = orc.hit_scene(objs, ray, 0.001, float("inf"), F32)
     assert int(v["hit_scene"][0]) == ids[0] and np.float32(v["hit_scene"][1]) == np.float32(t[0]) and int(v["hit_scene"][2]) == ff[0]
     assert np.array_equal(f("hit_point").astype(np.float32), pn[0, :3].astype(np.float32))
     assert np.array_equal(f("hit_normal").astype(np.float32), pn[0, 3:].astype(np.float32))
     # Shape::hit
-    r2 = np.array([[0.0, 0.0, 2.0, 0.1, -0.15, -1.0]])
+    d2 = np.array([0.1, -0.15, -1.0])
+    r2 = np.concatenate([[0.0, 0.0, 2.0], d2 / np.linalg.norm(d2)])[None]      # Ray::new_ normalises on the host, in f64
     for key, ob in (("sphere_hit", pt.make_objects([(0, [0.4, -0.6, -2.0, 0.4], 0, [0.5] * 3)])),
                     ("tri_hit", pt.make_objects([(1, [-1, -1, -3, 1, -1, -3, 1, 1, -3], 0, [0.5] * 3)]))):
         ids, t, pn, ff = orc.hit_scene(ob, r2, 0.001, float("inf"), F32)

@@ -67,3 +67,27 @@ def test_constants_match_the_header():
     for m in re.finditer(r"(PT_(?:OK|ERR|SHAPE|MAT|INTEGRATOR|ACCEL)_?\w*)\s*=\s*(\d+)", hdr):
         assert re.search(r"pub const %s: \w+ = %s;" % (m.group(1), m.group(2)), RUST), m.group(1)
     assert re.search(r"#define PT_ABI_VERSION (\d+)", HEADER).group(1) == re.search(r"PT_ABI_VERSION: u32 = (\d+);", RUST).group(1)
+
+
+def test_reference_patch_applies(tmp_path):
+    """rust/reference-shim/reference-gpu.patch (describe() on the traits, Camera::to_pod, gpu::render in main) must
+    apply to the reference's sources.  Only where the reference is present (this container; not the GPU box)."""
+    import shutil
+    import subprocess
+    import pytest
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("reference sources not present")
+    patch = os.path.join(ROOT, "rust", "reference-shim", "reference-gpu.patch")
+    touched = sorted(set(re.findall(r"^\+\+\+ b/(\S+)", open(patch).read(), flags=re.M)))
+    assert "src/main.rs" in touched and "src/objects/shape.rs" in touched and "src/objects/material.rs" in touched
+    for f in touched:
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        shutil.copy(os.path.join(ref, f), tmp_path / f)
+    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # every impl of the two traits in the reference gets a description (or the trait's default)
+    shape_impls = len(re.findall(r"^impl Shape for", open(os.path.join(ref, "src/objects/shape.rs")).read(), flags=re.M))
+    assert open(patch).read().count("fn describe(&self) -> (u32, [f64; 9])") == shape_impls + 1        # + the trait itself
+    gpu_rs = open(os.path.join(ROOT, "rust", "reference-shim", "gpu.rs")).read()
+    assert "unsafe" not in gpu_rs.replace("forbid(unsafe_code)", "").replace("`unsafe`", "")
