@@ -352,24 +352,34 @@ template <class R> inline bool sphere_hit(const Obj<R>& s, const Ray<R>& ray, R 
     V3<R> oc = ray.origin - s.center;
     R a = ray.direction.dot(ray.direction);
     R half_b = oc.dot(ray.direction);
-    R disc;
+    R disc, root;
     if (Ar<R>::kFloat) {
-        // f32 mode: half_b^2 - a*c cancels catastrophically for a small sphere far from the
-        // origin (abs error ~|oc|^2 * 2^-24 against r^2).  Algebraically identical, robust form
-        // (Haines et al., Ray Tracing Gems ch. 7): disc = a * (r^2 - |oc - (half_b/a) d|^2).
-        R k = half_b * (R(1) / a);
-        V3<R> l = madd(ray.direction, -k, oc);
-        disc = a * (s.radius * s.radius - l.dot(l));
+        // f32 arithmetic specification (device-equivalent):
+        //  * a = 1: every ray of the path is a unit vector (Ray::new normalises, camera.rs:10-16), so the
+        //    multiplications by a and 1/a of the general quadratic are dropped (SURVEY 8a row a5 prices the
+        //    test that way: "16 if a = 1 and r^2 cached");
+        //  * half_b^2 - c cancels catastrophically for a small sphere far from the origin (abs error
+        //    ~|oc|^2 * 2^-24 against r^2): algebraically identical, robust form (Haines et al., Ray Tracing
+        //    Gems ch. 7) disc = r^2 - |oc - half_b d|^2.
+        V3<R> l = madd(ray.direction, -half_b, oc);
+        disc = s.radius * s.radius - l.dot(l);
+        if (disc < 0) return false;
+        R sqrtd = std::sqrt(disc);
+        root = -half_b - sqrtd;
+        if (root < t_min || t_max < root) {
+            root = -half_b + sqrtd;
+            if (root < t_min || t_max < root) return false;
+        }
     } else {
         R c = oc.dot(oc) - s.radius * s.radius;
         disc = half_b * half_b - a * c;
-    }
-    if (disc < 0) return false;
-    R sqrtd = std::sqrt(disc);
-    R root = Ar<R>::rcp_div(-half_b - sqrtd, a);
-    if (root < t_min || t_max < root) {
-        root = Ar<R>::rcp_div(-half_b + sqrtd, a);
-        if (root < t_min || t_max < root) return false;
+        if (disc < 0) return false;
+        R sqrtd = std::sqrt(disc);
+        root = Ar<R>::rcp_div(-half_b - sqrtd, a);
+        if (root < t_min || t_max < root) {
+            root = Ar<R>::rcp_div(-half_b + sqrtd, a);
+            if (root < t_min || t_max < root) return false;
+        }
     }
     V3<R> point = ray.at(root);
     V3<R> outward = (point - s.center) / s.radius;

@@ -42,22 +42,23 @@ namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ primitive tests
 // SphereShape::hit (shape.rs:53-82) against the running closest t.  s = (center, r^2).
+// Every ray the scans see is a unit vector (Ray::new normalises, camera.rs:10-16; so do the entries that take rays
+// from outside), so the reference's a = d.d is 1 up to rounding and the f32 arithmetic specification takes a = 1: no
+// multiplication by a or 1/a (SURVEY 8a row a5 prices the test that way: "16 if a = 1 and r^2 cached").
 // ORDERED (BVH traversal, which meets the primitives in tree order): among equal t the highest object index
 // wins -- what the scan's "accept t <= closest" gives when it walks the objects in index order.
 template <bool ORDERED = false>
-PT_DEV void sphere_test(float4 s, f3 o, f3 d, float a, float inv_a, float t_min, float& closest, int& id, int obj) {
+PT_DEV void sphere_test(float4 s, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
     f3 oc = o - mk(s.x, s.y, s.z);
     float half_b = dot(oc, d);
-    // half_b^2 - a*c cancels catastrophically in f32 for a small sphere far from the origin;
-    // same quantity, robust form: a * (r^2 - |oc - (half_b/a) d|^2)  (Ray Tracing Gems ch. 7)
-    float k = half_b * inv_a;
-    f3 l = madd(d, -k, oc);
-    float q = s.w - dot(l, l);
-    float disc = a * q;
+    // half_b^2 - c cancels catastrophically in f32 for a small sphere far from the origin;
+    // same quantity, robust form: r^2 - |oc - half_b d|^2  (Ray Tracing Gems ch. 7)
+    f3 l = madd(d, -half_b, oc);
+    float disc = s.w - dot(l, l);
     if (disc < 0.0f) return;                       // NaN falls through, as in the reference (Q10)
     float sqrtd = pt_sqrt(disc);
-    float root1 = (-half_b - sqrtd) * inv_a;
-    float root2 = (-half_b + sqrtd) * inv_a;
+    float root1 = -half_b - sqrtd;
+    float root2 = -half_b + sqrtd;
     // shape.rs:76-82: take the near root unless it is out of range, then the far one.  root2 >= root1,
     // so "closest < root1" already rejects both; hence the candidate is root2 only when root1 < t_min.
     float c = root1 < t_min ? root2 : root1;
@@ -87,11 +88,10 @@ PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& c
 }
 
 // disc of SphereShape::hit only (the part every sphere pays), see sphere_test
-PT_DEV float sphere_disc(float4 s, f3 o, f3 d, float a, float inv_a) {
+PT_DEV float sphere_disc(float4 s, f3 o, f3 d) {
     f3 oc = o - mk(s.x, s.y, s.z);
-    float k = dot(oc, d) * inv_a;
-    f3 l = madd(d, -k, oc);
-    return a * (s.w - dot(l, l));
+    f3 l = madd(d, -dot(oc, d), oc);
+    return s.w - dot(l, l);
 }
 
 // GROUPED (large scenes, where a given sphere is rarely hit): four discriminants, ONE wave-uniform
@@ -99,24 +99,24 @@ PT_DEV float sphere_disc(float4 s, f3 o, f3 d, float a, float inv_a) {
 // sequential tests run only then.  max() drops NaNs unless all four are NaN, which is exactly the
 // NaN-ray case the reference lets through (Q10), so a NaN still reaches sphere_test.
 template <bool GROUPED>
-PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float a,
-                     float inv_a, float t_min, float& closest, int& id) {
+PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float t_min,
+                     float& closest, int& id) {
     if (tag == SHAPE_SPHERE) {
         // four LDS reads in flight per wait instead of one
         uint32_t i = 0;
         for (; i + 4u <= n; i += 4u) {
             float4 s0 = p[i], s1 = p[i + 1], s2 = p[i + 2], s3 = p[i + 3];
             if (GROUPED) {
-                float m = __builtin_fmaxf(__builtin_fmaxf(sphere_disc(s0, o, d, a, inv_a), sphere_disc(s1, o, d, a, inv_a)),
-                                          __builtin_fmaxf(sphere_disc(s2, o, d, a, inv_a), sphere_disc(s3, o, d, a, inv_a)));
+                float m = __builtin_fmaxf(__builtin_fmaxf(sphere_disc(s0, o, d), sphere_disc(s1, o, d)),
+                                          __builtin_fmaxf(sphere_disc(s2, o, d), sphere_disc(s3, o, d)));
                 if (__ballot(!(m < 0.0f)) == 0ull) continue;
             }
-            sphere_test(s0, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
-            sphere_test(s1, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 1);
-            sphere_test(s2, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 2);
-            sphere_test(s3, o, d, a, inv_a, t_min, closest, id, first_obj + (int)i + 3);
+            sphere_test(s0, o, d, t_min, closest, id, first_obj + (int)i);
+            sphere_test(s1, o, d, t_min, closest, id, first_obj + (int)i + 1);
+            sphere_test(s2, o, d, t_min, closest, id, first_obj + (int)i + 2);
+            sphere_test(s3, o, d, t_min, closest, id, first_obj + (int)i + 3);
         }
-        for (; i < n; ++i) sphere_test(p[i], o, d, a, inv_a, t_min, closest, id, first_obj + (int)i);
+        for (; i < n; ++i) sphere_test(p[i], o, d, t_min, closest, id, first_obj + (int)i);
     } else {
         for (uint32_t i = 0; i < n; ++i) {
             float4 a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
@@ -186,8 +186,6 @@ PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max
 template <int MODE>
 PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
     constexpr bool SMALL = MODE == kModeLds;
-    float a = dot(d, d);
-    float inv_a = pt_rcp(a);
     float closest = t_max;
     int id = -1;
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
@@ -198,7 +196,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
         run.count = __builtin_amdgcn_readfirstlane(run.count); run.off4 = __builtin_amdgcn_readfirstlane(run.off4);
         const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
         if (SMALL) {
-            scan_run<false>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
+            scan_run<false>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
         } else {
             float4* tile = const_cast<float4*>(sc.scan);
             const uint32_t tile_prims = kTileF4 / per;
@@ -208,7 +206,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
                 const float4* src = sc.scan_global + run.off4 + p0 * per;
                 for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) tile[k] = src[k];
                 __syncthreads();
-                scan_run<true>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, a, inv_a, t_min, closest, id);
+                scan_run<true>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, t_min, closest, id);
             }
         }
     }
@@ -217,13 +215,11 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
 }
 // the same scan with every record read from global memory (no LDS, no barrier: any subset of lanes may call it)
 PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
-    float a = dot(d, d);
-    float inv_a = pt_rcp(a);
     float closest = t_max;
     int id = -1;
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
         const Run run = sc.runs_global[r];
-        scan_run<false>(sc.scan_global + run.off4, run.tag, run.count, (int)run.first_obj, o, d, a, inv_a, t_min, closest, id);
+        scan_run<false>(sc.scan_global + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
     }
     id_out = id;
     t_out = closest;
@@ -723,7 +719,7 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
     // slab planes as one FMA each: t = plane * inv + b with bp = -(o + pad) * inv for the lower plane of a box and
     // bm = -(o - pad) * inv for the upper one (the rounding of b moves a plane by <= ulp(|o|), far inside pad)
     f3 o = parked_origin(), d = parked_dir(), inv = mk(0.f, 0.f, 0.f), bp = inv, bm = inv;
-    float a = 1.0f, inv_a = 1.0f, closest = 0.0f;
+    float closest = 0.0f;
     int id = -1;
     for (;;) {
         // ---- hand the next slots to the idle lanes, in lane order
@@ -736,8 +732,7 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                 if (!TMAX_IN_RAY || r1.w != 0.0f) {
                     slot = cand;
                     o = mk(r0.x, r0.y, r0.z); d = mk(r0.w, r1.x, r1.y);
-                    a = dot(d, d);
-                    inv_a = pt_rcp(a);
+                    const float a = dot(d, d), inv_a = __builtin_amdgcn_rcpf(a);      // only to recognise zero / NaN rays
                     closest = t_max;
                     id = -1;
                     const float o1 = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
@@ -819,7 +814,7 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                     for (uint32_t i = 0; i < kBvhMaxLeaf; ++i) {
                         if (i < cnt) {
                             if ((int)w[i] >= 0) {
-                                sphere_test<true>(r0[i], o, d, a, inv_a, t_min, closest, id, (int)w[i]);
+                                sphere_test<true>(r0[i], o, d, t_min, closest, id, (int)w[i]);
                             } else {
                                 const float4* rec = sc.bvh.rec + 3u * (first + i);
                                 const float4 r1 = rec[1], r2 = rec[2];
