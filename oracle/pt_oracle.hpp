@@ -444,23 +444,39 @@ inline void sphere_sample(const Obj<R>& s, const Hit<R>& from, const Hit<R>* tar
         R sphi, cphi;
         Ar<R>::sincos2pi(r2, sphi, cphi);
         V3<R> w = to_center.normalize();
-        V3<R> up = std::fabs(w.y) > R(0.999) ? V3<R>(1, 0, 0) : V3<R>(0, 1, 0);
-        V3<R> u = up.cross(w).normalize();
-        V3<R> v = w.cross(u);
-        V3<R> direction = frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta);
-        Ray<R> sample_ray(from.point, direction);
-        V3<R> oc = sample_ray.origin - s.center;
-        // NB the reference uses the UN-normalised `direction` for a, half_b but
-        // sample_ray.at(t) uses the normalised one (shape.rs:130-137).
-        R a = direction.dot(direction);
-        R half_b = oc.dot(direction);
-        R c = oc.dot(oc) - s.radius * s.radius;
-        R disc = Ar<R>::kFloat ? Ar<R>::mad(half_b, half_b, -(a * c)) : half_b * half_b - a * c;
-        // DELIBERATE DEVIATION: the reference takes sqrt(disc)
-        // unguarded (shape.rs:136); a cone-edge sample whose disc rounds below
-        // zero would give a NaN light point.  Clamped at 0 here and on the device.
-        R t = Ar<R>::rcp_div(-half_b - std::sqrt(std::fmax(disc, R(0))), a);
-        point = sample_ray.at(t);
+        if (Ar<R>::kFloat) {
+            // f32 specification: the frame as in frame_of; the direction is normalised once (Ray::new, shape.rs:128)
+            // and that unit vector serves the whole quadratic (a = 1; the reference mixes the un-normalised
+            // vector for a, half_b with the normalised one for ray.at, shape.rs:130-137); discriminant in the robust
+            // form of sphere_hit (same quantity as half_b^2 - c), clamped at 0 (unguarded sqrt).
+            V3<R> u, v;
+            frame_of(w, u, v);
+            V3<R> direction = frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta).normalize();
+            V3<R> oc = from.point - s.center;
+            R half_b = oc.dot(direction);
+            V3<R> l = madd(direction, -half_b, oc);
+            R disc = s.radius * s.radius - l.dot(l);
+            R t = -half_b - std::sqrt(std::fmax(disc, R(0)));
+            point = madd(direction, t, from.point);
+        } else {
+            V3<R> up = std::fabs(w.y) > R(0.999) ? V3<R>(1, 0, 0) : V3<R>(0, 1, 0);
+            V3<R> u = up.cross(w).normalize();
+            V3<R> v = w.cross(u);
+            V3<R> direction = frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta);
+            Ray<R> sample_ray(from.point, direction);
+            V3<R> oc = sample_ray.origin - s.center;
+            // NB the reference uses the UN-normalised `direction` for a, half_b but
+            // sample_ray.at(t) uses the normalised one (shape.rs:130-137).
+            R a = direction.dot(direction);
+            R half_b = oc.dot(direction);
+            R c = oc.dot(oc) - s.radius * s.radius;
+            R disc = half_b * half_b - a * c;
+            // DELIBERATE DEVIATION: the reference takes sqrt(disc)
+            // unguarded (shape.rs:136); a cone-edge sample whose disc rounds below
+            // zero would give a NaN light point.  Clamped at 0 here and on the device.
+            R t = (-half_b - std::sqrt(std::fmax(disc, R(0)))) / a;
+            point = sample_ray.at(t);
+        }
     }
     normal = (point - s.center).normalize();
     V3<R> light_dir = point - from.point;
@@ -502,6 +518,18 @@ inline void shape_sample(const Obj<R>& o, const Hit<R>& from, const Hit<R>* targ
 // ------------------------------------------------------------------ materials
 // local frame used by every sampler: material.rs:112-119, mirror.rs:21-27
 template <class R> inline void frame_of(const V3<R>& n, V3<R>& tangent, V3<R>& bitangent) {
+    if (Ar<R>::kFloat) {
+        // f32 specification: up x n written out for the two constant `up` vectors -- X x n = (0, -n.z, n.y),
+        // Y x n = (n.z, 0, -n.x) -- instead of a general cross product with selected constants: the same values
+        // (a zero component may differ in sign), seven operations fewer.
+        const bool use_x = std::fabs(n.y) > R(0.999);
+        V3<R> raw = use_x ? V3<R>(R(0), -n.z, n.y) : V3<R>(n.z, R(0), -n.x);
+        R len2 = Ar<R>::mad(raw.z, raw.z, n.z * n.z);        // = raw . raw: the other component is +-n.z in both cases
+        R len = std::sqrt(len2);
+        tangent = len > 0 ? raw / len : raw;                 // math.rs:48-51
+        bitangent = n.cross(tangent);
+        return;
+    }
     V3<R> up = std::fabs(n.y) > R(0.999) ? V3<R>(1, 0, 0) : V3<R>(0, 1, 0);
     tangent = up.cross(n).normalize();
     bitangent = n.cross(tangent);

@@ -204,6 +204,16 @@ PT_DEV Hit finish_hit(const float4* __restrict__ shape, int id, uint32_t shape_t
 }
 
 // ------------------------------------------------------------------ shape sampling (shape.rs)
+// local frame: material.rs:112-119, mirror.rs:21-27
+// up x n written out for the two constant `up` vectors: X x n = (0, -n.z, n.y), Y x n = (n.z, 0, -n.x)
+PT_DEV void frame_of(f3 n, f3& tangent, f3& bitangent) {
+    const bool use_x = __builtin_fabsf(n.y) > 0.999f;
+    const f3 raw = mk(use_x ? 0.0f : n.z, use_x ? -n.z : 0.0f, use_x ? n.y : -n.x);
+    const float len2 = __builtin_fmaf(raw.z, raw.z, n.z * n.z);      // raw . raw: the other component is +-n.z in both cases
+    const float len = pt_sqrt(len2);
+    tangent = len > 0.0f ? raw / len : raw;                          // math.rs:48-51
+    bitangent = cross(n, tangent);
+}
 // SphereShape::sample_surface_from_point, shape.rs:91-145.  with_target: the MIS
 // look-ahead form (point given, no draws).
 PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float r1, float r2, f3& point,
@@ -227,19 +237,17 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
     float sphi, cphi;
     sincos2pi(r2, sphi, cphi);
     f3 w = normalize(to_center);
-    f3 up = __builtin_fabsf(w.y) > 0.999f ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
-    f3 u = normalize(cross(up, w));
-    f3 v = cross(w, u);
-    f3 direction = frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta);
-    f3 rd = normalize(direction);                       // Ray::new normalises (camera.rs:13)
+    f3 u, v;
+    frame_of(w, u, v);
+    // normalised once (Ray::new, shape.rs:128); that unit vector serves the whole quadratic (a = 1)
+    f3 direction = normalize(frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta));
     f3 oc = from - center;
-    float a = dot(direction, direction);                // un-normalised direction, shape.rs:131-132
     float half_b = dot(oc, direction);
-    float c = dot(oc, oc) - radius * radius;
-    float disc = __builtin_fmaf(half_b, half_b, -(a * c));
+    f3 l = madd(direction, -half_b, oc);                // discriminant in the robust form of sphere_test
+    float disc = radius * radius - dot(l, l);
     // deliberate deviation: disc clamped at 0 (reference: unguarded sqrt, shape.rs:136)
-    float t = (-half_b - pt_sqrt(__builtin_fmaxf(disc, 0.0f))) * pt_rcp(a);
-    point = madd(rd, t, from);
+    float t = -half_b - pt_sqrt(__builtin_fmaxf(disc, 0.0f));
+    point = madd(direction, t, from);
 }
 // TriangleShape::sample_surface_from_point, shape.rs:200-242
 PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 target, float r1, float r2,
@@ -280,12 +288,6 @@ PT_DEV void shape_sample(const float4* __restrict__ shape, int id, uint32_t shap
 }
 
 // ------------------------------------------------------------------ materials
-// local frame: material.rs:112-119, mirror.rs:21-27
-PT_DEV void frame_of(f3 n, f3& tangent, f3& bitangent) {
-    f3 up = __builtin_fabsf(n.y) > 0.999f ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
-    tangent = normalize(cross(up, n));
-    bitangent = cross(n, tangent);
-}
 // cosine-weighted direction: material.rs:93-122 / :267-295
 PT_DEV f3 cosine_sample(f3 n, float r1, float r2) {
     float sphi, cphi;
