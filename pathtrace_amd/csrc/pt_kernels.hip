@@ -47,7 +47,10 @@ namespace PTK_IMPL {
 // multiplication by a or 1/a (SURVEY 8a row a5 prices the test that way: "16 if a = 1 and r^2 cached").
 // ORDERED (BVH traversal, which meets the primitives in tree order): among equal t the highest object index
 // wins -- what the scan's "accept t <= closest" gives when it walks the objects in index order.
-template <bool ORDERED = false>
+// ANY (visibility scans): only "is anything accepted" is asked (rendering.rs:62-65 tests is_none()), and the first
+// accepted object of the shrinking scan is tested against the initial t_max, so every test runs against that fixed
+// bound and nothing is tracked but a flag: id >= 0.
+template <bool ORDERED = false, bool ANY = false>
 PT_DEV void sphere_test(float4 s, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
     f3 oc = o - mk(s.x, s.y, s.z);
     float half_b = dot(oc, d);
@@ -63,12 +66,13 @@ PT_DEV void sphere_test(float4 s, f3 o, f3 d, float t_min, float& closest, int& 
     // so "closest < root1" already rejects both; hence the candidate is root2 only when root1 < t_min.
     float c = root1 < t_min ? root2 : root1;
     if (c < t_min || closest < c) return;          // NaN is accepted, as in the reference
+    if (ANY) { id = 0; return; }
     if (ORDERED && c == closest && obj < id) return;
     closest = c;
     id = obj;
 }
 // TriangleShape::hit (shape.rs:161-192), Moeller-Trumbore; e1, e2 precomputed.
-template <bool ORDERED = false>
+template <bool ORDERED = false, bool ANY = false>
 PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
     f3 h = cross(d, e2);
     float a = dot(e1, h);
@@ -82,6 +86,7 @@ PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& c
     if (v < 0.0f || u + v > 1.0f) return;
     float t = f * dot(e2, q);
     if (t < t_min || t > closest) return;
+    if (ANY) { id = 0; return; }
     if (ORDERED && t == closest && obj < id) return;
     closest = t;
     id = obj;
@@ -98,7 +103,7 @@ PT_DEV float sphere_disc(float4 s, f3 o, f3 d) {
 // branch "did any lane hit any of the four?" instead of a divergent branch per sphere; the exact
 // sequential tests run only then.  max() drops NaNs unless all four are NaN, which is exactly the
 // NaN-ray case the reference lets through (Q10), so a NaN still reaches sphere_test.
-template <bool GROUPED>
+template <bool GROUPED, bool ANY = false>
 PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float t_min,
                      float& closest, int& id) {
     if (tag == SHAPE_SPHERE) {
@@ -111,16 +116,16 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
                                           __builtin_fmaxf(sphere_disc(s2, o, d), sphere_disc(s3, o, d)));
                 if (__ballot(!(m < 0.0f)) == 0ull) continue;
             }
-            sphere_test(s0, o, d, t_min, closest, id, first_obj + (int)i);
-            sphere_test(s1, o, d, t_min, closest, id, first_obj + (int)i + 1);
-            sphere_test(s2, o, d, t_min, closest, id, first_obj + (int)i + 2);
-            sphere_test(s3, o, d, t_min, closest, id, first_obj + (int)i + 3);
+            sphere_test<false, ANY>(s0, o, d, t_min, closest, id, first_obj + (int)i);
+            sphere_test<false, ANY>(s1, o, d, t_min, closest, id, first_obj + (int)i + 1);
+            sphere_test<false, ANY>(s2, o, d, t_min, closest, id, first_obj + (int)i + 2);
+            sphere_test<false, ANY>(s3, o, d, t_min, closest, id, first_obj + (int)i + 3);
         }
-        for (; i < n; ++i) sphere_test(p[i], o, d, t_min, closest, id, first_obj + (int)i);
+        for (; i < n; ++i) sphere_test<false, ANY>(p[i], o, d, t_min, closest, id, first_obj + (int)i);
     } else {
         for (uint32_t i = 0; i < n; ++i) {
             float4 a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
-            triangle_test(mk(a0.x, a0.y, a0.z), mk(a1.x, a1.y, a1.z), mk(a2.x, a2.y, a2.z), o, d, t_min, closest, id,
+            triangle_test<false, ANY>(mk(a0.x, a0.y, a0.z), mk(a1.x, a1.y, a1.z), mk(a2.x, a2.y, a2.z), o, d, t_min, closest, id,
                           first_obj + (int)i);
         }
     }
@@ -183,7 +188,7 @@ PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max
 // shrinking t_max.  kModeLds: the whole scan array already sits in LDS.  kModeTiled:
 // every run is streamed through one LDS tile; the loop is block-uniform (all
 // threads of the workgroup call this together, active or not).
-template <int MODE>
+template <int MODE, bool ANY = false>
 PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
     constexpr bool SMALL = MODE == kModeLds;
     float closest = t_max;
@@ -196,7 +201,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
         run.count = __builtin_amdgcn_readfirstlane(run.count); run.off4 = __builtin_amdgcn_readfirstlane(run.off4);
         const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
         if (SMALL) {
-            scan_run<false>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
+            scan_run<false, ANY>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
         } else {
             float4* tile = const_cast<float4*>(sc.scan);
             const uint32_t tile_prims = kTileF4 / per;
@@ -206,7 +211,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
                 const float4* src = sc.scan_global + run.off4 + p0 * per;
                 for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) tile[k] = src[k];
                 __syncthreads();
-                scan_run<true>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, t_min, closest, id);
+                scan_run<true, ANY>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, t_min, closest, id);
             }
         }
     }
@@ -625,7 +630,7 @@ k_paths(BounceArgs a) {
                 f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
                 f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                 int sid; float st;
-                scan_closest<MODE>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                scan_closest<MODE, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);   // any-hit form
                 visible = v.need_shadow && sid < 0;
                 wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
