@@ -172,10 +172,12 @@ def test_hit_records_device_function(pt, orc, gpu_ctx, scene, arg, accel):
         ids, rec = gpu_ctx.debug_hit_records(rays, exact_math=exact, accel=accel)
         same = (ids == ids64) & (ids >= 0)
         assert same.sum() >= 0.999 * (ids64 >= 0).sum()
-        # point: f32 resolves a ray parameter t to ~1e-7 t (the rays of this test also start outside the box and hit
-        # the R = 100 wall spheres up to t = 200 away); grazing hits are ill-conditioned: bulk and worst case
+        # point: the bar of the hit-distance tests, |dt| <= 1e-4 t + 2e-5 (the absolute floor is the R = 100 wall spheres
+        # of C2: o - c is only good to ulp(100) = 7.6e-6 in f32), with room for the direction's own rounding; grazing
+        # hits are ill-conditioned: bulk and worst case
         dp = np.abs(rec[same, 1:4] - pn64[same, 0:3]).max(1)
-        assert np.mean(dp <= 2e-5 + 2e-6 * t64[same]) >= 0.995 and dp.max() <= 2e-2, (np.mean(dp <= 2e-5 + 2e-6 * t64[same]), dp.max())
+        tol = 5e-5 + 1e-4 * t64[same]
+        assert np.mean(dp <= tol) >= 0.999 and dp.max() <= 2e-2, (np.mean(dp <= tol), dp.max())
         assert np.mean(np.abs(rec[same, 4:7] - pn64[same, 3:6]).max(1) <= 2e-3) >= 0.995          # normal (R = 0.005 spheres: 1/r amplifies)
         assert np.mean((rec[same, 7] != 0) == (ff64[same] != 0)) >= 0.9999
 
