@@ -57,7 +57,7 @@ class PtTuning(C.Structure):
         ("export_below", C.c_uint32),
         ("bvh_refill", C.c_uint32),
         ("bvh_leaf", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("cont_workgroups", C.c_uint32),
     ]
 
 

@@ -64,9 +64,11 @@ constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
 constexpr uint32_t kPathsPerWaveLds = 672;
 constexpr uint32_t kPathsPerWave = 1024;
 constexpr uint32_t kMinGrid = 256 * 8;         // level-0 launches: at least this many workgroups (small renders)
-// continuation launches: one resident round at 6 waves/SIMD.  Their paths are sparse survivors; more, emptier
-// segments cost lane utilisation (measured on C2, ms per step: 1536 -> 9.40, 2048 -> 9.47, 3072 -> 9.69, 6144 -> 10.18)
-constexpr uint32_t kContGrid = 256 * 6;
+// continuation launches: their paths are sparse survivors, and a wave-iteration costs the same however few of its
+// lanes carry a path, so more, emptier segments cost time -- and so do too few waves (latency of ~35 dependent passes).
+// Measured on C2 / C1, ms of the continuation launch: 96 workgroups 1.75 / 5.0, 192 0.98 / 2.7, 384 0.60 / 1.6,
+// 768 0.44 / 1.16, 1024 0.46, 1536 0.51 / 1.19, 3072 0.69 (round 1: 6144 -> +0.8).
+constexpr uint32_t kContGrid = 1024;
 constexpr uint32_t kExportSmall = 64;          // a wave hands its segment over when fewer paths than this are left
                                                // (measured 32 ... 256: no difference beyond noise on C1 and C2)
 // Tail hand-off: in launches of more than kExportMinPaths paths a wave whose segment falls below one chunk
@@ -517,7 +519,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // Tail hand-off: the level-0 launch of a large batch exports what its waves have left below one chunk; ONE
     // continuation launch of fixed size takes that queue up.  It reads the count on the device.
     const bool hand_off = !inject && n_paths_max > kExportMinPaths;
-    const uint32_t nw_cont = kContGrid * kWavesPerBlock;
+    const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
+    const uint32_t nw_cont = cont_grid * kWavesPerBlock;
     // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup
     // (= 64 per wave) from a workgroup-shared one
     const size_t ovf_slots = (size_t)nw * std::max(export_small, 64u) + 64u;
@@ -611,7 +614,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             a.src_mode = inject ? 1u : 0u;
             a.export_below = hand_off ? (small_scene ? export_small : ptk::kBlock) : 1u;
             if (level > 0) {
-                g = kContGrid;
+                g = cont_grid;
                 a.n_first = 0; a.n_first_dev = d_count;
                 a.seg_cap = seg_cap_cont;
                 a.src_mode = 1u;

@@ -70,7 +70,7 @@ pub struct PtTuning {
     pub export_below: u32,
     pub bvh_refill: u32,
     pub bvh_leaf: u32,
-    pub reserved: u32,
+    pub cont_workgroups: u32,
 }
 
 #[repr(C)]
