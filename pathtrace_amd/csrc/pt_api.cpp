@@ -128,10 +128,10 @@ struct PtContext {
     hipStream_t side_stream = nullptr;
     DevBuf<float4> cqueue[4];
     DevBuf<float4> caux, csray[2];    // ... and, for accel = 1, its own staged-pass scratch
-    DevBuf<float4> lsamp2;
+    DevBuf<ptk::Rgb> lsamp2;
     hipEvent_t ev_l0[2] = {nullptr, nullptr}, ev_resolved[2] = {nullptr, nullptr};
     uint32_t* h_ovf = nullptr;        // pinned read-back of one counter
-    DevBuf<float4> lsamp;
+    DevBuf<ptk::Rgb> lsamp;
     DevBuf<unsigned long long> dstats;
     DevBuf<double> film;
     DevBuf<float> host_lin;       // device staging of pt_render_host
@@ -596,7 +596,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         const uint32_t s0 = batch * nb_max;
         const uint32_t nb = std::min(nb_max, spp - s0);
         const int par = overlap ? (int)(batch & 1u) : 0;          // buffers of this batch
-        float4* const lsamp_b = par ? c->lsamp2.p : c->lsamp.p;
+        ptk::Rgb* const lsamp_b = par ? c->lsamp2.p : c->lsamp.p;
         a.s_base = prm->spp_offset + s0;
         a.lsamp = lsamp_b;
         // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
@@ -1020,13 +1020,13 @@ int pt_render_pixels(PtContext* c, const PtCamera* cam, const PtRenderParams* pr
     int rc = render_to_host(c, cam, prm, FilmState{}, &lr, n, out_linear, out_rgba);
     if (rc || !out_samples || !n) return rc;
     // the batch's per-path radiance buffer, index = sample * n + pixel  ->  [pixel][sample][rgb]
-    std::vector<float4> ls((size_t)n * prm->spp);
-    HIP_TRY(hipMemcpy(ls.data(), c->lsamp.p, ls.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<ptk::Rgb> ls((size_t)n * prm->spp);
+    HIP_TRY(hipMemcpy(ls.data(), c->lsamp.p, ls.size() * sizeof(ptk::Rgb), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i)
         for (uint32_t sidx = 0; sidx < prm->spp; ++sidx) {
-            const float4 v = ls[(size_t)sidx * n + i];
+            const ptk::Rgb v = ls[(size_t)sidx * n + i];
             float* o = out_samples + ((size_t)i * prm->spp + sidx) * 3;
-            o[0] = v.x; o[1] = v.y; o[2] = v.z;
+            o[0] = v.r; o[1] = v.g; o[2] = v.b;
         }
     return PT_OK;
 }

@@ -644,7 +644,7 @@ k_paths(BounceArgs a) {
         const bool alive = vertex_end<MIS, DIFFUSE, SMALL>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
 
         // ---- retire, or compact in place into the wave's own segment
-        if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
+        if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
         const unsigned long long mask = __ballot(alive);
         uint32_t cnt_before = 0, cnt_all = (uint32_t)__popcll(mask);
         if (!SMALL) {
@@ -941,7 +941,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             vertex_begin<MIS, DIFFUSE>(sc, p, active, __float_as_int(h.x), h.y, sample, kx, py, v);
             const bool visible = MIS && v.need_shadow && h.z == 0.0f;
             const bool alive = vertex_end<MIS, DIFFUSE, false>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
-            if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = make_float4(p.L.x, p.L.y, p.L.z, 0.0f);
+            if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
             const unsigned long long mask = __ballot(alive);
             if (alive) store_state(q, out_n + lane_rank(mask), p);
             out_n += (uint32_t)__popcll(mask);
@@ -1026,8 +1026,8 @@ __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
     double r = 0.0, g = 0.0, b = 0.0;
     if (a.load_film) { r = a.film[3 * (size_t)p]; g = a.film[3 * (size_t)p + 1]; b = a.film[3 * (size_t)p + 2]; }
     for (uint32_t s = 0; s < a.nb; ++s) {
-        float4 v = a.lsamp[(size_t)s * a.np + p];
-        r += (double)v.x; g += (double)v.y; b += (double)v.z;                     // world.rs:311
+        const Rgb v = a.lsamp[(size_t)s * a.np + p];
+        r += (double)v.r; g += (double)v.g; b += (double)v.b;                     // world.rs:311
     }
     if (a.store_film) { a.film[3 * (size_t)p] = r; a.film[3 * (size_t)p + 1] = g; a.film[3 * (size_t)p + 2] = b; }
     if (!a.finalize) return;

@@ -364,3 +364,20 @@ def test_multi_gpu_partition_pack_unpack_for_n_devices(pt, gpu_ctx, n):
     for band_rows in (0, 1, 10, 117):
         lin, rgba = gpu_ctx.multi_emulate(n, cam, pt.default_params(spp=5, band_rows=band_rows))
         assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8), (n, band_rows)
+
+
+def test_large_pixel_list_takes_the_tail_hand_off(pt, gpu_ctx):
+    """A pixel list large enough for the two-launch form (level-0 launch exports, continuation launch reads its count
+    on the device) in the LIST variants of the kernels: every pixel of a 512 x 512 image, shuffled, 24 spp = 6.3 M paths
+    (> 2^22).  Equals the full film, pixel by pixel."""
+    gpu_ctx.upload(pt.builtin_scene(1))
+    cam = pt.camera_new(width=512, height=512)
+    prm = pt.default_params(spp=24)
+    full, full8 = gpu_ctx.render(cam, prm)
+    rng = np.random.default_rng(12)
+    order = rng.permutation(512 * 512)
+    xy = np.stack([order % 512, order // 512], 1).astype(np.uint32)
+    lin, rgba, _ = gpu_ctx.render_pixels(cam, prm, xy)
+    st = gpu_ctx.stats()
+    assert st.bounce_launches == 2 and st.samples == 512 * 512 * 24
+    assert np.array_equal(lin, full.cpu().numpy()[xy[:, 1], xy[:, 0]]) and np.array_equal(rgba, full8.cpu().numpy()[xy[:, 1], xy[:, 0]])
