@@ -112,7 +112,8 @@ struct PtContext {
     // BVH (PtRenderParams.accel): built from the host copy of the shape records at first use
     std::vector<float4> h_shape;
     std::vector<uint32_t> h_shape_tag;
-    DevBuf<float4> bvh_nodes, bvh_rec;
+    DevBuf<uint4> bvh_nodes;
+    DevBuf<float4> bvh_rec;
     DevBuf<uint32_t> bvh_ids;
     bool has_bvh = false;
     bool bvh_refused = false;         // the scene has a non-finite object: PT_ACCEL_AUTO stays with the linear scan
@@ -228,16 +229,17 @@ int ensure_bvh(PtContext* c) {
         return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
     }
     int rc;
-    if ((rc = c->bvh_nodes.ensure(b.nodes.size() + 4)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
+    if ((rc = c->bvh_nodes.ensure(b.qnodes.size() + 2)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
         (rc = c->bvh_ids.ensure(b.leaf_ids.size() + 1)))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!b.nodes.empty()) HIP_TRY(hipMemcpy(c->bvh_nodes.p, b.nodes.data(), b.nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!b.qnodes.empty()) HIP_TRY(hipMemcpy(c->bvh_nodes.p, b.qnodes.data(), b.qnodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
     if (!b.leaf_rec.empty()) HIP_TRY(hipMemcpy(c->bvh_rec.p, b.leaf_rec.data(), b.leaf_rec.size() * sizeof(float4), hipMemcpyHostToDevice));
     if (!b.leaf_ids.empty()) HIP_TRY(hipMemcpy(c->bvh_ids.p, b.leaf_ids.data(), b.leaf_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->view.bvh.nodes = c->bvh_nodes.p; c->view.bvh.rec = c->bvh_rec.p; c->view.bvh.ids = c->bvh_ids.p;
     c->view.bvh.root = b.root;
     c->view.bvh.scene_abs = b.scene_abs;
+    for (int k = 0; k < 3; ++k) { c->view.bvh.grid_min[k] = b.grid_min[k]; c->view.bvh.grid_cell[k] = b.grid_cell[k]; }
     c->bvh_depth = b.depth;
     c->has_bvh = true;
     return PT_OK;
@@ -907,9 +909,23 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
             if (4 * (size_t)code + 3 >= b.nodes.size()) { err = "node index out of bounds"; return false; }
             const float4 n0 = b.nodes[4 * (size_t)code], n1 = b.nodes[4 * (size_t)code + 1], n2 = b.nodes[4 * (size_t)code + 2],
                          n3 = b.nodes[4 * (size_t)code + 3];
-            const float blo[2][3] = {{n0.x, n0.y, n0.z}, {n1.z, n1.w, n2.x}}, bhi[2][3] = {{n0.w, n1.x, n1.y}, {n2.y, n2.z, n2.w}};
+            const float flo[2][3] = {{n0.x, n0.y, n0.z}, {n1.z, n1.w, n2.x}}, fhi[2][3] = {{n0.w, n1.x, n1.y}, {n2.y, n2.z, n2.w}};
             uint32_t cc[2];
             std::memcpy(&cc[0], &n3.x, 4); std::memcpy(&cc[1], &n3.y, 4);
+            // what the device traverses: the boxes decoded from the 16-bit grid; they must contain the f32 boxes
+            if (2 * (size_t)code + 1 >= b.qnodes.size()) { err = "quantised node index out of bounds"; return false; }
+            const uint4 qa = b.qnodes[2 * (size_t)code], qb = b.qnodes[2 * (size_t)code + 1];
+            if (qb.z != cc[0] || qb.w != cc[1]) { err = "quantised node carries other child codes"; return false; }
+            const uint32_t qw[2][3] = {{qa.x, qa.y, qa.z}, {qa.w, qb.x, qb.y}};
+            float blo[2][3], bhi[2][3];
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t q[6] = {qw[c][0] & 0xFFFFu, qw[c][0] >> 16, qw[c][1] & 0xFFFFu, qw[c][1] >> 16, qw[c][2] & 0xFFFFu, qw[c][2] >> 16};
+                for (int k = 0; k < 3; ++k) {
+                    blo[c][k] = std::fmaf((float)q[k], b.grid_cell[k], b.grid_min[k]);
+                    bhi[c][k] = std::fmaf((float)q[3 + k], b.grid_cell[k], b.grid_min[k]);
+                    if (!(blo[c][k] <= flo[c][k] && bhi[c][k] >= fhi[c][k])) { err = "quantised child box does not contain the f32 box"; return false; }
+                }
+            }
             for (int c = 0; c < 2; ++c) {
                 double cl[3], ch[3];
                 if (!walk(cc[c], d + 1, cl, ch)) return false;

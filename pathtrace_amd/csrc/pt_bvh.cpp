@@ -133,6 +133,57 @@ struct Builder {
     }
 };
 
+// Child boxes -> 16-bit grid coordinates over the bounds of all child boxes (see pt_bvh.h).
+void quantise(Built& t) {
+    const size_t n_nodes = t.nodes.size() / 4;
+    t.qnodes.assign(2 * n_nodes, make_uint4(0, 0, 0, 0));
+    if (n_nodes == 0) return;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    auto boxes = [&](size_t k, float blo[2][3], float bhi[2][3]) {
+        const float4 n0 = t.nodes[4 * k], n1 = t.nodes[4 * k + 1], n2 = t.nodes[4 * k + 2];
+        const float l[2][3] = {{n0.x, n0.y, n0.z}, {n1.z, n1.w, n2.x}}, h[2][3] = {{n0.w, n1.x, n1.y}, {n2.y, n2.z, n2.w}};
+        std::memcpy(blo, l, sizeof l); std::memcpy(bhi, h, sizeof h);
+    };
+    for (size_t k = 0; k < n_nodes; ++k) {
+        float blo[2][3], bhi[2][3];
+        boxes(k, blo, bhi);
+        for (int c = 0; c < 2; ++c)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)blo[c][a]); hi[a] = std::max(hi[a], (double)bhi[c][a]); }
+    }
+    for (int a = 0; a < 3; ++a) {
+        t.grid_min[a] = down(lo[a]);
+        const double ext = std::max(hi[a] - (double)t.grid_min[a], 1e-30);
+        t.grid_cell[a] = up(ext / 65535.0 * (1.0 + 1e-6));          // 65535 cells reach past the upper bound
+    }
+    auto decode = [&](int a, uint32_t q) { return std::fmaf((float)q, t.grid_cell[a], t.grid_min[a]); };
+    auto q_lo = [&](int a, float v) {
+        long q = (long)std::floor(((double)v - t.grid_min[a]) / t.grid_cell[a]);
+        q = std::min(std::max(q, 0L), 65535L);
+        while (q > 0 && decode(a, (uint32_t)q) > v) --q;
+        return (uint32_t)q;
+    };
+    auto q_hi = [&](int a, float v) {
+        long q = (long)std::ceil(((double)v - t.grid_min[a]) / t.grid_cell[a]);
+        q = std::min(std::max(q, 0L), 65535L);
+        while (q < 65535 && decode(a, (uint32_t)q) < v) ++q;
+        return (uint32_t)q;
+    };
+    for (size_t k = 0; k < n_nodes; ++k) {
+        float blo[2][3], bhi[2][3];
+        boxes(k, blo, bhi);
+        uint32_t w[2][3];
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t lx = q_lo(0, blo[c][0]), ly = q_lo(1, blo[c][1]), lz = q_lo(2, blo[c][2]);
+            const uint32_t hx = q_hi(0, bhi[c][0]), hy = q_hi(1, bhi[c][1]), hz = q_hi(2, bhi[c][2]);
+            w[c][0] = lx | (ly << 16); w[c][1] = lz | (hx << 16); w[c][2] = hy | (hz << 16);
+        }
+        uint32_t c0, c1;
+        std::memcpy(&c0, &t.nodes[4 * k + 3].x, 4); std::memcpy(&c1, &t.nodes[4 * k + 3].y, 4);
+        t.qnodes[2 * k] = make_uint4(w[0][0], w[0][1], w[0][2], w[1][0]);
+        t.qnodes[2 * k + 1] = make_uint4(w[1][1], w[1][2], c0, c1);
+    }
+}
+
 }  // namespace
 
 Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n) {
@@ -180,6 +231,7 @@ Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n) {
         b.out.root = b.build(0, n, 0, &root);
     }
     b.out.scene_abs = up(amax[0] + amax[1] + amax[2]);
+    quantise(b.out);
     return std::move(b.out);
 }
 

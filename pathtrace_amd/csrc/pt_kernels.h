@@ -18,7 +18,8 @@ struct Run {
 
 // Optional BVH over the objects (pt_bvh.h); built on the host the first time a render asks for it.
 struct BvhView {
-    const float4* nodes;     // 4 float4 per internal node: the two child boxes + child codes
+    const uint4* nodes;      // 2 uint4 per internal node: the two child boxes on the 16-bit grid + child codes (pt_bvh.h)
+    float grid_min[3], grid_cell[3];   // box coordinate = grid_min + q * grid_cell
     const float4* rec;       // 3 float4 per leaf slot (scan record of the primitive)
     const uint32_t* ids;     // object index per leaf slot (bit 31: triangle)
     uint32_t root;           // child code of the root

@@ -723,7 +723,12 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
     uint32_t slot = 0, node = 0xFFFFFFFFu, sp = 1;
     // slab planes as one FMA each: t = plane * inv + b with bp = -(o + pad) * inv for the lower plane of a box and
     // bm = -(o - pad) * inv for the upper one (the rounding of b moves a plane by <= ulp(|o|), far inside pad)
+    // ... with the plane on the builder's 16-bit grid, plane = grid_min + q * cell: t = q * (cell * inv) + b, b now from
+    // (grid_min - (o +- pad)) * inv.  The folded form rounds differently from "decode, then slab", by ~1e-7 of the
+    // scene extent: far inside pad as well.
     f3 o = parked_origin(), d = parked_dir(), inv = mk(0.f, 0.f, 0.f), bp = inv, bm = inv;
+    const f3 gmin = mk(sc.bvh.grid_min[0], sc.bvh.grid_min[1], sc.bvh.grid_min[2]);
+    const f3 gcell = mk(sc.bvh.grid_cell[0], sc.bvh.grid_cell[1], sc.bvh.grid_cell[2]);
     float closest = 0.0f;
     int id = -1;
     for (;;) {
@@ -749,8 +754,9 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                         inv = mk(__builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(d.x), -1e25f), 1e25f),
                                  __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(d.y), -1e25f), 1e25f),
                                  __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rcpf(d.z), -1e25f), 1e25f));
-                        bp = mk(-(o.x + pad) * inv.x, -(o.y + pad) * inv.y, -(o.z + pad) * inv.z);
-                        bm = mk(-(o.x - pad) * inv.x, -(o.y - pad) * inv.y, -(o.z - pad) * inv.z);
+                        bp = mk((gmin.x - (o.x + pad)) * inv.x, (gmin.y - (o.y + pad)) * inv.y, (gmin.z - (o.z + pad)) * inv.z);
+                        bm = mk((gmin.x - (o.x - pad)) * inv.x, (gmin.y - (o.y - pad)) * inv.y, (gmin.z - (o.z - pad)) * inv.z);
+                        inv = inv * gcell;                                    // from here on: per grid step
                         stk[0] = 0xFFFFFFFFu;
                         sp = 1;
                         node = sc.bvh.root;
@@ -771,24 +777,26 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
         const uint32_t low_water = next < n ? refill_below : 1u;
         do {
             if (has && (int)node >= 0) {                 // internal node: test both child boxes
-                const float4* nd = sc.bvh.nodes + 4u * node;
-                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                float ax0 = __builtin_fmaf(n0.x, inv.x, bp.x), ax1 = __builtin_fmaf(n0.w, inv.x, bm.x);
-                float ay0 = __builtin_fmaf(n0.y, inv.y, bp.y), ay1 = __builtin_fmaf(n1.x, inv.y, bm.y);
-                float az0 = __builtin_fmaf(n0.z, inv.z, bp.z), az1 = __builtin_fmaf(n1.y, inv.z, bm.z);
+                const uint4* nd = sc.bvh.nodes + 2u * node;
+                const uint4 qa = nd[0], qb = nd[1];
+                // child 0: words qa.x (lo.x | lo.y << 16), qa.y (lo.z | hi.x << 16), qa.z (hi.y | hi.z << 16)
+                float ax0 = __builtin_fmaf((float)(qa.x & 0xFFFFu), inv.x, bp.x), ax1 = __builtin_fmaf((float)(qa.y >> 16), inv.x, bm.x);
+                float ay0 = __builtin_fmaf((float)(qa.x >> 16), inv.y, bp.y), ay1 = __builtin_fmaf((float)(qa.z & 0xFFFFu), inv.y, bm.y);
+                float az0 = __builtin_fmaf((float)(qa.y & 0xFFFFu), inv.z, bp.z), az1 = __builtin_fmaf((float)(qa.z >> 16), inv.z, bm.z);
                 const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
                                                   __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
                 const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
                                                   __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
-                ax0 = __builtin_fmaf(n1.z, inv.x, bp.x); ax1 = __builtin_fmaf(n2.y, inv.x, bm.x);
-                ay0 = __builtin_fmaf(n1.w, inv.y, bp.y); ay1 = __builtin_fmaf(n2.z, inv.y, bm.y);
-                az0 = __builtin_fmaf(n2.x, inv.z, bp.z); az1 = __builtin_fmaf(n2.w, inv.z, bm.z);
+                // child 1: words qa.w, qb.x, qb.y
+                ax0 = __builtin_fmaf((float)(qa.w & 0xFFFFu), inv.x, bp.x); ax1 = __builtin_fmaf((float)(qb.x >> 16), inv.x, bm.x);
+                ay0 = __builtin_fmaf((float)(qa.w >> 16), inv.y, bp.y); ay1 = __builtin_fmaf((float)(qb.y & 0xFFFFu), inv.y, bm.y);
+                az0 = __builtin_fmaf((float)(qb.x & 0xFFFFu), inv.z, bp.z); az1 = __builtin_fmaf((float)(qb.y >> 16), inv.z, bm.z);
                 const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
                                                   __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
                 const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
                                                   __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
                 const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y);
+                const uint32_t c0 = qb.z, c1 = qb.w;
                 if (h0 && h1) {
                     const bool swap = tn1 < tn0;               // nearer child first
                     stk[sp * kBlock] = swap ? c0 : c1;
