@@ -122,8 +122,8 @@ typedef struct {
 /* Scheduling knobs of a context (pt_context_set_tuning); results never depend on them.  0 = library default.   */
 typedef struct {
     uint32_t export_below;   /* a wave hands its queue segment to the continuation launch below this many paths (64) */
-    uint32_t bvh_refill;     /* accel = 1: idle lanes take new rays when fewer lanes than this are tracing (36)      */
-    uint32_t bvh_leaf;       /* accel = 1: leaf primitives are tested when this many lanes wait at a leaf (24)       */
+    uint32_t bvh_refill;     /* accel = 1: idle lanes take new rays when fewer lanes than this are tracing (44)      */
+    uint32_t bvh_leaf;       /* accel = 1: leaf primitives are tested when this many lanes wait at a leaf (20)       */
     uint32_t cont_workgroups;/* workgroups of the continuation launch that finishes the handed-over tails             */
 } PtTuning;
 

@@ -114,8 +114,8 @@ constexpr uint32_t kBlock = 256;
 // through one LDS tile and gather shape/material records from global memory.
 constexpr uint32_t kSmallObjs = 128;
 constexpr uint32_t kTileF4 = 1920;         // 30 KiB LDS tile (divisible by 3: whole triangles); 5 workgroups per CU (measured: 2550 / 4 -> 1214 ms, 1920 / 5 -> 1106 ms on C4)
-constexpr uint32_t kRefillBelow = 36;      // BVH traversal: hand out new rays when fewer lanes than this are tracing
-constexpr uint32_t kLeafBatch = 24;        // BVH traversal: test leaf primitives when at least this many lanes wait at a leaf
+constexpr uint32_t kRefillBelow = 44;      // BVH traversal: hand out new rays when fewer lanes than this are tracing
+constexpr uint32_t kLeafBatch = 20;        // BVH traversal: test leaf primitives when at least this many lanes wait at a leaf
 constexpr uint32_t kBvhMaxLeaf = 4;        // primitives per BVH leaf the traversal unrolls for (= ptbvh::kMaxLeaf)
 constexpr uint32_t kBvhStack = 24;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 24 KiB per workgroup, 5 workgroups per CU
 
