@@ -162,3 +162,69 @@ def test_maximum_sizes(pt, orc, gpu_ctx):
     lin, _ = gpu_ctx.render(cam, pt.default_params(spp=1, exact_math=1, band_rows=35000, band_index=1, band_count=2))
     ref, _, _ = orc.render(cam, objs, pt.default_params(spp=1, band_rows=35000, band_index=1, band_count=2), orc.F32, orc.ITERATIVE, 16)
     assert lin.shape[0] == 35000 and np.array_equal(lin.cpu().numpy(), ref.astype(np.float32))
+
+
+def test_soak_mixed_entries_stay_deterministic(pt, gpu_ctx):
+    """Forty calls in random order through every rendering entry of one context -- whole frames of changing size,
+    spp, integrator, accel and arithmetic, band tiles, pixel lists, injected rays, multi-batch renders, progressive
+    renders -- interleaved with scene changes.  Every call is made twice (not back to back): the second result must equal
+    the first bit for bit, i.e. no entry leaves state behind that another one picks up."""
+    rng = np.random.default_rng(2026)
+    scenes = [pt.builtin_scene(1), pt.builtin_scene(2), pt.builtin_scene(4, 700)]
+    jobs = []
+    for k in range(20):
+        sc = int(rng.integers(0, 3))
+        w, h = int(rng.integers(8, 200)), int(rng.integers(8, 120))
+        kind = ["frame", "frame", "tile", "pixels", "rays", "batches", "progressive"][int(rng.integers(0, 7))]
+        jobs.append((sc, w, h, kind, int(rng.integers(1, 9)), int(rng.integers(0, 2)), int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 1000))))
+
+    def run(job):
+        sc, w, h, kind, spp, integ, accel, exact, seed = job
+        gpu_ctx.upload(scenes[sc])
+        cam = pt.camera_new(width=w, height=h)
+        r = np.random.default_rng(seed)
+        if kind == "frame":
+            lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=spp, integrator=integ, accel=accel, exact_math=exact))
+            return lin.cpu().numpy(), rgba.cpu().numpy()
+        if kind == "tile":
+            lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=spp, integrator=integ, accel=accel, band_rows=3, band_index=1, band_count=2))
+            return lin.cpu().numpy(), rgba.cpu().numpy()
+        if kind == "pixels":
+            xy = np.stack([r.integers(0, w, 50), r.integers(0, h, 50)], 1)
+            lin, rgba, smp = gpu_ctx.render_pixels(cam, pt.default_params(spp=spp, integrator=integ, accel=accel, exact_math=exact), xy, want_samples=True)
+            return lin, rgba, smp
+        if kind == "rays":
+            rays = np.concatenate([r.uniform(-0.9, 0.9, (64, 3)) + [0, 0, -2], r.normal(size=(64, 3))], 1)
+            return (gpu_ctx.ray_color(pt.default_params(spp=1, spp_offset=spp, integrator=integ, accel=accel), rays, r.integers(0, 400, (64, 2))),)
+        if kind == "batches":
+            lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=spp + 3, integrator=integ, accel=accel, max_paths_in_flight=w * h * 2))
+            assert gpu_ctx.stats().batches >= 2
+            return lin.cpu().numpy(), rgba.cpu().numpy()
+        lin, rgba = gpu_ctx.render_progressive(cam, pt.default_params(spp=spp + 2, integrator=integ, accel=accel), 2)
+        return lin, rgba
+
+    first = {}
+    order = list(range(len(jobs))) * 2
+    rng.shuffle(order)
+    for k in order:
+        out = run(jobs[k])
+        assert all(np.isfinite(o).all() for o in out), jobs[k]
+        if k in first:
+            assert all(np.array_equal(a, b) for a, b in zip(first[k], out)), jobs[k]
+        else:
+            first[k] = out
+
+
+def test_multi_device_objects_can_be_created_and_destroyed_repeatedly(pt):
+    """pt_multi_create / destroy in a loop (contexts, RCCL communicator, events): no failure, frames stay the same."""
+    objs = pt.builtin_scene(2)
+    cam = pt.camera_new(width=64, height=48)
+    ref = None
+    for k in range(4):
+        m = pt.Multi([0])
+        m.upload(objs)
+        lin, rgba = m.render_host(cam, pt.default_params(spp=3, band_rows=5))
+        m.close()
+        if ref is None:
+            ref = (lin, rgba)
+        assert np.array_equal(lin, ref[0]) and np.array_equal(rgba, ref[1])
