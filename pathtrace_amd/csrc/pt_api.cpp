@@ -113,7 +113,7 @@ struct PtContext {
     std::vector<float4> h_shape;
     std::vector<uint32_t> h_shape_tag;
     DevBuf<uint4> bvh_nodes;
-    DevBuf<float4> bvh_rec;
+    DevBuf<float4> bvh_rec, bvh_lead;
     DevBuf<uint32_t> bvh_ids;
     bool has_bvh = false;
     bool bvh_refused = false;         // the scene has a non-finite object: PT_ACCEL_AUTO stays with the linear scan
@@ -230,13 +230,14 @@ int ensure_bvh(PtContext* c) {
     }
     int rc;
     if ((rc = c->bvh_nodes.ensure(b.qnodes.size() + 2)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
-        (rc = c->bvh_ids.ensure(b.leaf_ids.size() + 1)))
+        (rc = c->bvh_ids.ensure(b.leaf_ids.size() + 4)) || (rc = c->bvh_lead.ensure(b.leaf_lead.size() + 4)))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!b.qnodes.empty()) HIP_TRY(hipMemcpy(c->bvh_nodes.p, b.qnodes.data(), b.qnodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
     if (!b.leaf_rec.empty()) HIP_TRY(hipMemcpy(c->bvh_rec.p, b.leaf_rec.data(), b.leaf_rec.size() * sizeof(float4), hipMemcpyHostToDevice));
     if (!b.leaf_ids.empty()) HIP_TRY(hipMemcpy(c->bvh_ids.p, b.leaf_ids.data(), b.leaf_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    c->view.bvh.nodes = c->bvh_nodes.p; c->view.bvh.rec = c->bvh_rec.p; c->view.bvh.ids = c->bvh_ids.p;
+    if (!b.leaf_lead.empty()) HIP_TRY(hipMemcpy(c->bvh_lead.p, b.leaf_lead.data(), b.leaf_lead.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->view.bvh.nodes = c->bvh_nodes.p; c->view.bvh.rec = c->bvh_rec.p; c->view.bvh.ids = c->bvh_ids.p; c->view.bvh.lead = c->bvh_lead.p;
     c->view.bvh.root = b.root;
     c->view.bvh.scene_abs = b.scene_abs;
     for (int k = 0; k < 3; ++k) { c->view.bvh.grid_min[k] = b.grid_min[k]; c->view.bvh.grid_cell[k] = b.grid_cell[k]; }
@@ -317,7 +318,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
-    c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release();
+    c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release(); c->bvh_lead.release();
     c->bvh_aux.release(); c->bvh_sray[0].release(); c->bvh_sray[1].release();
     for (auto& b : c->queue) b.release();
     for (auto& par : c->ovf) for (auto& q : par) for (auto& b : q) b.release();
@@ -860,10 +861,11 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
     const ptbvh::Built b = ptbvh::build(shape.data(), tag.data(), n);
     if (depth) *depth = b.depth;
     if (n_nodes) *n_nodes = (uint32_t)(b.nodes.size() / 4);
-    if (n_leaf_slots) *n_leaf_slots = (uint32_t)b.leaf_ids.size();
+    if (n_leaf_slots) *n_leaf_slots = b.leaf_prims;          // slots that hold a primitive (leaves are padded to multiples of 4 slots)
     if (b.non_finite) return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate", b.non_finite);
     if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", b.depth);
-    if (b.leaf_ids.size() != n || b.leaf_rec.size() != 3 * (size_t)n) return fail(PT_ERR_UNSUPPORTED, "%zu leaf slots for %u objects", b.leaf_ids.size(), n);
+    if (b.leaf_prims != n || b.leaf_rec.size() != 3 * b.leaf_ids.size() || b.leaf_lead.size() != b.leaf_ids.size() || b.leaf_ids.size() % 4u != 0u)
+        return fail(PT_ERR_UNSUPPORTED, "%u primitives in %zu leaf slots for %u objects", b.leaf_prims, b.leaf_ids.size(), n);
     if (n == 0) return b.root == ptbvh::kDone ? PT_OK : fail(PT_ERR_UNSUPPORTED, "empty scene: root is not the sentinel");
     // boxes of the primitives in f64 from the same f32 records the device tests
     auto prim_box = [&](uint32_t o, double lo[3], double hi[3]) {
@@ -892,7 +894,7 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
             if (code == ptbvh::kDone) { err = "sentinel inside the tree"; return false; }
             if (code & ptbvh::kLeafBit) {
                 const uint32_t first = code & 0x0FFFFFFFu, cnt = ((code >> 28) & 7u) + 1u;
-                if (cnt > ptbvh::kMaxLeaf || (size_t)first + cnt > b.leaf_ids.size()) { err = "leaf range out of bounds"; return false; }
+                if (cnt > ptbvh::kMaxLeaf || (size_t)first + cnt > b.leaf_ids.size() || first % 4u != 0u) { err = "leaf range out of bounds or not aligned to 4 slots"; return false; }
                 for (uint32_t i = first; i < first + cnt; ++i) {
                     const uint32_t w = b.leaf_ids[i], o = w & 0x7FFFFFFFu;
                     if (o >= n || seen[o]) { err = "object missing or in two leaves"; return false; }
@@ -900,6 +902,7 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
                     if (((w >> 31) != 0) != (tag[o] == PT_SHAPE_TRIANGLE)) { err = "leaf tag bit differs from the object's shape"; return false; }
                     const int ns = tag[o] == PT_SHAPE_TRIANGLE ? 3 : 1;
                     if (std::memcmp(&b.leaf_rec[3 * (size_t)i], &scan[3 * (size_t)o], ns * sizeof(float4)) != 0) { err = "leaf record differs from the scan record"; return false; }
+                    if (std::memcmp(&b.leaf_lead[i], &scan[3 * (size_t)o], sizeof(float4)) != 0) { err = "lead record differs from the scan record"; return false; }
                     double pl[3], ph[3];
                     pbox(o, pl, ph);
                     for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], pl[k]); hi[k] = std::max(hi[k], ph[k]); }

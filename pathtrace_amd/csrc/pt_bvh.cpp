@@ -47,6 +47,11 @@ struct Builder {
     Built out;
 
     uint32_t make_leaf(uint32_t first, uint32_t count, uint32_t depth) {
+        while (out.leaf_ids.size() % 4u != 0u) {                 // leaves start at multiples of 4 slots
+            out.leaf_ids.push_back(kDone);
+            out.leaf_lead.push_back(make_float4(0, 0, 0, 0));
+            for (int k = 0; k < 3; ++k) out.leaf_rec.push_back(make_float4(0, 0, 0, 0));
+        }
         const uint32_t slot = (uint32_t)out.leaf_ids.size();
         // object order inside a leaf (not needed for correctness, keeps the tests in scan order)
         std::sort(prims.begin() + first, prims.begin() + first + count, [](const Prim& a, const Prim& b) { return a.obj < b.obj; });
@@ -57,6 +62,8 @@ struct Builder {
             float4 r0 = shape[3 * (size_t)o], r1 = shape[3 * (size_t)o + 1], r2 = shape[3 * (size_t)o + 2];
             if (!tri) { r0.w = r0.w * r0.w; r1 = make_float4(0, 0, 0, 0); r2 = r1; }   // (c, r^2): the scan record of a sphere
             out.leaf_rec.push_back(r0); out.leaf_rec.push_back(r1); out.leaf_rec.push_back(r2);
+            out.leaf_lead.push_back(r0);
+            out.leaf_prims++;
         }
         out.depth = std::max(out.depth, depth);
         return kLeafBit | ((count - 1u) << 28) | slot;
@@ -231,6 +238,11 @@ Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n) {
         b.out.root = b.build(0, n, 0, &root);
     }
     b.out.scene_abs = up(amax[0] + amax[1] + amax[2]);
+    while (b.out.leaf_ids.size() % 4u != 0u) {                   // the last leaf's 16-byte id load stays in bounds
+        b.out.leaf_ids.push_back(kDone);
+        b.out.leaf_lead.push_back(make_float4(0, 0, 0, 0));
+        for (int k = 0; k < 3; ++k) b.out.leaf_rec.push_back(make_float4(0, 0, 0, 0));
+    }
     quantise(b.out);
     return std::move(b.out);
 }

@@ -34,8 +34,12 @@ struct Built {
     // the exact one (it only prunes less).
     std::vector<uint4> qnodes;
     float grid_min[3] = {0.f, 0.f, 0.f}, grid_cell[3] = {0.f, 0.f, 0.f};
+    // Leaf slots.  Every leaf starts at a slot index that is a multiple of 4 (unused slots: id kDone), so the <= 4 ids of
+    // a leaf are one aligned 16-byte load and its <= 4 lead records one 64-byte line.
     std::vector<float4> leaf_rec;     // 3 float4 per leaf slot: sphere (c, r^2), -, - ; triangle v0, e1, e2 (the scan records)
+    std::vector<float4> leaf_lead;    // 1 float4 per leaf slot = leaf_rec[3 * slot]: all a sphere test reads (a triangle reads e1, e2 from leaf_rec)
     std::vector<uint32_t> leaf_ids;   // object index of the leaf slot (| kTriangleBit)
+    uint32_t leaf_prims = 0;          // slots that hold a primitive (= number of objects)
     uint32_t root = kDone;            // child code of the root
     uint32_t depth = 0;               // deepest leaf (root = 0)
     float scene_abs = 0.0f;           // sum over axes of the largest |coordinate| of any box: scale of the traversal padding

@@ -20,8 +20,9 @@ struct Run {
 struct BvhView {
     const uint4* nodes;      // 2 uint4 per internal node: the two child boxes on the 16-bit grid + child codes (pt_bvh.h)
     float grid_min[3], grid_cell[3];   // box coordinate = grid_min + q * grid_cell
-    const float4* rec;       // 3 float4 per leaf slot (scan record of the primitive)
-    const uint32_t* ids;     // object index per leaf slot (bit 31: triangle)
+    const float4* rec;       // 3 float4 per leaf slot (scan record of the primitive); the traversal reads e1, e2 of triangles here
+    const float4* lead;      // 1 float4 per leaf slot = rec[3 * slot]: sphere (c, r^2) / triangle v0 -- a leaf's <= 4 are one 64-byte line
+    const uint32_t* ids;     // object index per leaf slot (bit 31: triangle); a leaf starts at a multiple of 4: one 16-byte load
     uint32_t root;           // child code of the root
     float scene_abs;         // scale of the padding the slab test applies (see bvh_scan)
 };

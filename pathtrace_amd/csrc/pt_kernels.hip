@@ -814,15 +814,13 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
             if (leafs != 0ull && ((uint32_t)__popcll(leafs) >= leaf_batch || __ballot(has && (int)node >= 0) == 0ull)) {
                 if (at_leaf) {
                     const uint32_t first = node & 0x0FFFFFFFu, cnt = ((node >> 28) & 7u) + 1u;
-                    // all (<= 4) records requested before the first test: one memory latency per leaf
-                    uint32_t w[kBvhMaxLeaf];
+                    // all ids (one aligned 16-byte load) and lead records (one 64-byte line) requested before the
+                    // first test: one memory latency per leaf
+                    const uint4 idv = *reinterpret_cast<const uint4*>(sc.bvh.ids + first);
+                    const uint32_t w[kBvhMaxLeaf] = {idv.x, idv.y, idv.z, idv.w};
                     float4 r0[kBvhMaxLeaf];
 #pragma unroll
-                    for (uint32_t i = 0; i < kBvhMaxLeaf; ++i) {
-                        const uint32_t k = first + (i < cnt ? i : 0u);
-                        w[i] = sc.bvh.ids[k];
-                        r0[i] = sc.bvh.rec[3u * k];
-                    }
+                    for (uint32_t i = 0; i < kBvhMaxLeaf; ++i) r0[i] = sc.bvh.lead[first + (i < cnt ? i : 0u)];
 #pragma unroll
                     for (uint32_t i = 0; i < kBvhMaxLeaf; ++i) {
                         if (i < cnt) {
