@@ -21,10 +21,10 @@ which = sys.argv[1:] or ["c1", "c2", "c3", "c4s", "c5"]
 if "c1" in which: run("C1 ref Cornell+glass", pt.builtin_scene(1), 1024, 1024, 64)
 if "c1s" in which: run("C1 config0", pt.builtin_scene(1), 256, 256, 4)
 if "c2" in which: run("C2", pt.builtin_scene(2), 1024, 1024, 64)
-if "c3" in which: run("C3", pt.builtin_scene(2), 1024, 1024, 4096, reps=1)
+if "c3" in which: run("C3", pt.builtin_scene(2), 1024, 1024, 4096, reps=2)
 if "c4s" in which: run("C4 (4 spp probe)", pt.builtin_scene(4, 10000), 1024, 1024, 4, reps=1, accel=0)
 if "c4" in which: run("C4 (linear scan)", pt.builtin_scene(4, 10000), 1024, 1024, 256, reps=1, accel=0)
-if "c5" in which: run("C5 on one GPU", pt.builtin_scene(2), 3840, 2160, 64, reps=1)
+if "c5" in which: run("C5 on one GPU", pt.builtin_scene(2), 3840, 2160, 64, reps=3)
 if "c4m" in which: run("C4 (64 spp, linear scan)", pt.builtin_scene(4, 10000), 1024, 1024, 64, reps=1, accel=0)
 if "c4b" in which: run("C4 BVH (64 spp)", pt.builtin_scene(4, 10000), 1024, 1024, 64, reps=2, accel=1)
 if "c4bf" in which: run("C4 BVH", pt.builtin_scene(4, 10000), 1024, 1024, 256, reps=2, accel=1)
