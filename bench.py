@@ -137,6 +137,8 @@ def main():
                          "2 = PT_ACCEL_AUTO, the product default (the BVH for C4-sized scenes)")
     ap.add_argument("--cont-workgroups", type=int, default=0, help="PtTuning.cont_workgroups (0 = library default)")
     ap.add_argument("--export-below", type=int, default=0, help="PtTuning.export_below (0 = library default)")
+    ap.add_argument("--level0-form", type=int, default=0, help="PtTuning.level0_form (0 = library default, 1 = queue form, 2 = regenerating form)")
+    ap.add_argument("--regen-workgroups", type=int, default=0, help="PtTuning.regen_workgroups (0 = library default)")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (64*N spp) instead of the strong-scaling default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
@@ -183,7 +185,8 @@ def main():
                             max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
     ctx = pt.Context(dev_index)
     ctx.upload(objs)
-    ctx.set_tuning(cont_workgroups=args.cont_workgroups, export_below=args.export_below)
+    ctx.set_tuning(cont_workgroups=args.cont_workgroups, export_below=args.export_below, level0_form=args.level0_form,
+                   regen_workgroups=args.regen_workgroups)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     rows = pt.tile_rows(HEIGHT, band_rows, rank, world)
     lin = torch.empty((rows, WIDTH, 3), dtype=torch.float32, device=dev)

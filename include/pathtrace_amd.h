@@ -125,6 +125,10 @@ typedef struct {
     uint32_t bvh_refill;     /* accel = 1: idle lanes take new rays when fewer lanes than this are tracing (44)      */
     uint32_t bvh_leaf;       /* accel = 1: leaf primitives are tested when this many lanes wait at a leaf (20)       */
     uint32_t cont_workgroups;/* workgroups of the continuation launch that finishes the handed-over tails             */
+    uint32_t level0_form;    /* level-0 launch of a large batch over a scene in LDS.  0: paths stay in registers and a
+                                lane whose path ends takes the batch's next one (k_paths_regen) if every material is
+                                Lambertian or emissive, the queue form otherwise; 1: the queue form; 2: k_paths_regen  */
+    uint32_t regen_workgroups;/* workgroups of that regenerating launch (0: what the device holds at once)             */
 } PtTuning;
 
 /* Counters of the last render on a context. */

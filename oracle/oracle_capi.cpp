@@ -91,6 +91,7 @@ extern "C" int orc_render(const PtCamera* cam, const PtObject* objs, uint32_t n,
 
 extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 extern "C" double orc_u01(uint32_t r) { return u01(r); }
+extern "C" uint32_t orc_rr_word(const uint32_t ds[4]) { return rr_word(ds); }
 
 extern "C" void orc_camera_new(const double o[3], uint32_t w, uint32_t h, double dist, double fov, PtCamera* out) {
     camera_new(o, w, h, dist, fov, out);

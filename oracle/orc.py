@@ -44,6 +44,13 @@ def u01(r):
     return lib().orc_u01(C.c_uint32(r))
 
 
+def rr_word(ds):
+    """Roulette word of a vertex from its four BLK_SURFACE words (pt_oracle.hpp rr_word)."""
+    f = lib().orc_rr_word
+    f.restype = C.c_uint32
+    return int(f((C.c_uint32 * 4)(*[int(v) for v in ds])))
+
+
 def render(cam, objs, params, precision=F64, form=RECURSIVE, threads=1):
     """-> (linear float64[rows,W,3], rgba uint8[rows,W,4], counters dict)"""
     rows = lib().orc_tile_rows(C.c_uint32(cam.height), C.c_uint32(params.band_rows), C.c_uint32(params.band_index),

@@ -67,14 +67,16 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 
 // Draw blocks per vertex (the dimensions of SURVEY Appendix A, regrouped by HOW OFTEN a vertex needs them):
 //   block 0 (surface): [0] light r1 [1] light r2 [2] bsdf r1 [3] bsdf r2       -- every non-emitter vertex
-//   block 1 (choice):  [0] light index (raw u32) [1] Mirror lobe u [2] Russian roulette u [3] spare
-// Block 1 decides nothing at a vertex of a Lambertian / OrenNayar surface with one light in the scene and
-// depth < MIN_DEPTH (index = umulhi(u, 1) = 0; rr = 1 > every uniform): the device does not generate it there
-// (one Philox call per vertex instead of two for the first MIN_DEPTH bounces), the oracle always does.
+//   block 1 (choice):  [0] light index (raw u32) [1] Mirror lobe u [2], [3] spare
+// The Russian-roulette uniform of the vertex is made of the bits of block 0 that u01() does not look at (the low 9
+// of every word; Philox output bits are independent): rr_word().
+// Block 1 decides nothing at a vertex of a Lambertian / OrenNayar surface with one light in the scene
+// (index = umulhi(u, 1) = 0): the device does not generate it there (one Philox call per vertex instead of two), the
+// oracle always does.
 // Camera jitter: depth = 0xFFFFFFFF, block 0: [0] ox [1] oy   (world.rs:299: ox first)
 enum { BLK_SURFACE = 0, BLK_CHOICE = 1, DEPTH_CAMERA = 0xFFFFFFFFu };
 enum { DIM_LIGHT_R1 = 0, DIM_LIGHT_R2 = 1, DIM_BSDF_R1 = 2, DIM_BSDF_R2 = 3 };       // words of BLK_SURFACE
-enum { DIM_LIGHT_INDEX = 0, DIM_LOBE = 1, DIM_RR = 2 };                             // words of BLK_CHOICE
+enum { DIM_LIGHT_INDEX = 0, DIM_LOBE = 1 };                                         // words of BLK_CHOICE
 
 // 23-bit uniform on the OPEN interval (0,1): (2k+1)/2^24, exactly representable
 // in f32, so the float and double oracles and the device see the same value.
@@ -83,6 +85,9 @@ enum { DIM_LIGHT_INDEX = 0, DIM_LOBE = 1, DIM_RR = 2 };                         
 // (material.rs:104, rendering.rs:89), so excluding it changes nothing measurable
 // and removes the f32 singularities (SURVEY 8a "unprotected singularities").
 inline double u01(uint32_t r) { return (double)(((r >> 9) << 1) | 1u) * (1.0 / 16777216.0); }
+// The roulette word of a vertex from its BLK_SURFACE words: u01() of it reads the low 9 bits of word 0, the low 9 of
+// word 1 and bits 8..4 of word 2 -- none of which any other draw of the vertex looks at.
+inline uint32_t rr_word(const uint32_t ds[4]) { return (ds[0] << 23) | ((ds[1] & 0x1FFu) << 14) | ((ds[2] & 0x1FFu) << 5); }
 
 struct Draws {
     uint32_t key[2];   // (x, y): low/high word of the reference seed (y<<32)|x, main.rs:51
@@ -875,7 +880,7 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
     scattered.eta_ratio = eta_from_object(obj, hit);                               // :87
     V3<R> next_tp = throughput * bsdf * cos_theta / pdf;                           // :89
     R rr = rr_prob(p, depth, next_tp);                                             // :91-98
-    if ((R)u01(dc[DIM_RR]) > rr) return V3<R>::zero();                             // :100-102 (drops `total`, Q1)
+    if ((R)u01(rr_word(ds)) > rr) return V3<R>::zero();                             // :100-102 (drops `total`, Q1)
     Hit<R> h2;
     int o2 = hit_scene(w, scattered, tmin, kInf<R>(), h2);                         // :104-105
     cn.scans++;
@@ -925,7 +930,7 @@ V3<R> ray_color_brdf_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32
     scattered.eta_ratio = eta_from_object(obj, hit);
     V3<R> next_tp = throughput * bsdf * cos_theta / pdf;                           // :236
     R rr = rr_prob(p, depth, next_tp);
-    if ((R)u01(dc[DIM_RR]) > rr) return V3<R>::zero();                             // :246-248
+    if ((R)u01(rr_word(ds)) > rr) return V3<R>::zero();                             // :246-248
     V3<R> li = ray_color_brdf_rec(w, p, scattered, depth + 1, dr, next_tp / rr, cn);
     return bsdf * li * cos_theta / (pdf * rr);                                     // :260
 }
@@ -1013,8 +1018,8 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
         bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);
         V3<R> next_tp = beta * bsdf * cos_theta / pdf;
         R rr = rr_prob(p, depth, next_tp);
-        if (T) { T[18] = pdf; T[19] = rr; T[20] = (double)u01(dc[DIM_RR]); }
-        if ((R)u01(dc[DIM_RR]) > rr) break;              // drops `direct` too (Q1)
+        if (T) { T[18] = pdf; T[19] = rr; T[20] = (double)u01(rr_word(ds)); }
+        if ((R)u01(rr_word(ds)) > rr) break;              // drops `direct` too (Q1)
         L += beta * direct;
         if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
         beta = next_tp / rr;

@@ -58,6 +58,8 @@ class PtTuning(C.Structure):
         ("bvh_refill", C.c_uint32),
         ("bvh_leaf", C.c_uint32),
         ("cont_workgroups", C.c_uint32),
+        ("level0_form", C.c_uint32),
+        ("regen_workgroups", C.c_uint32),
     ]
 
 

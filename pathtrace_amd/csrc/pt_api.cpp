@@ -69,6 +69,9 @@ constexpr uint32_t kMinGrid = 256 * 8;         // level-0 launches: at least thi
 // Measured on C2 / C1, ms of the continuation launch: 96 workgroups 1.75 / 5.0, 192 0.98 / 2.7, 384 0.60 / 1.6,
 // 768 0.44 / 1.16, 1024 0.46, 1536 0.51 / 1.19, 3072 0.69 (round 1: 6144 -> +0.8).
 constexpr uint32_t kContGrid = 1024;
+constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
+constexpr uint32_t kRegenStatic16 = 4;         // k_paths_regen: sixteenths of a batch's chunks dealt round-robin, the rest by the counters
+constexpr uint32_t kRegenExportBelow = 16;     // ... and its waves hand over once the batch is used up and fewer paths than this are alive
 constexpr uint32_t kExportSmall = 64;          // a wave hands its segment over when fewer paths than this are left
                                                // (measured 32 ... 256: no difference beyond noise on C1 and C2)
 // Tail hand-off: in launches of more than kExportMinPaths paths a wave whose segment falls below one chunk
@@ -101,6 +104,7 @@ void pt_internal_multi_shutdown(void);
 
 struct PtContext {
     int device = 0;
+    uint32_t n_cus = 256;             // compute units of the device (grid of the regenerating level-0 launch)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     // scene
@@ -122,8 +126,8 @@ struct PtContext {
     // wavefront state
     DevBuf<float4> queue[4];
     DevBuf<float4> bvh_aux, bvh_sray[2];   // accel = 1: per-slot scratch of the staged passes (k_paths_bvh)
-    DevBuf<float4> ovf[2][2][4];      // overflow queues of the tail hand-off: [batch parity][level parity][plane]
-    DevBuf<uint32_t> ovf_count;       // [batch parity][level parity]
+    DevBuf<float4> ovf[2][2][4];      // overflow queues of the tail hand-off: per batch parity: leftover count, chunk counters (kCountStride)[plane]
+    DevBuf<uint32_t> ovf_count;       // per batch parity: leftover count, chunk counters (kCountStride)
     // multi-batch renders: the continuation launches and the film resolve of batch k run on side_stream while the
     // level-0 launch of batch k + 1 runs on the caller's stream (their own queue and a second sample buffer)
     hipStream_t side_stream = nullptr;
@@ -287,6 +291,10 @@ int pt_context_create(int device, PtContext** out) {
     HIP_TRY(hipSetDevice(device));
     PtContext* c = new PtContext();
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus;
+    }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(PT_ERR_HIP, "hipStreamCreateWithFlags failed");
@@ -522,16 +530,26 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // Tail hand-off: the level-0 launch of a large batch exports what its waves have left below one chunk; ONE
     // continuation launch of fixed size takes that queue up.  It reads the count on the device.
     const bool hand_off = !inject && n_paths_max > kExportMinPaths;
+    // Such a batch over a scene in LDS takes the regenerating level-0 kernel: paths live in registers, a lane whose
+    // path ends takes the next one of the batch; grid = the waves the device holds at once (k_paths_regen).
+    // (Scenes with GGX / OrenNayar surfaces keep the queue form unless asked: paths of every depth and material share a
+    // wave there, and the divergence costs what the form saves -- C1 12.40 vs 12.21 ms.)
+    const bool regen = (c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && c->view.diffuse_only)) && hand_off && !list &&
+                       !prm->accel && c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
+    const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups :
+                                c->n_cus * (c->view.diffuse_only ? ptk::kRegenWavesDiffuse : ptk::kRegenWavesGeneric));
     const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
     const uint32_t nw_cont = cont_grid * kWavesPerBlock;
     // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup
     // (= 64 per wave) from a workgroup-shared one
-    const size_t ovf_slots = (size_t)nw * std::max(export_small, 64u) + 64u;
+    const size_t ovf_slots = (size_t)(regen ? regen_grid * kWavesPerBlock : nw) * std::max(export_small, 64u) + 64u;
     const uint32_t seg_cap_cont = (uint32_t)((((ovf_slots + 63) / 64 + nw_cont - 1) / nw_cont) * 64u);
     const size_t q_slots_cont = hand_off ? (size_t)nw_cont * seg_cap_cont : 0;
-    const size_t q_slots = std::max((size_t)nw * seg_cap, q_slots_cont);
+    const size_t q_slots = regen ? std::max<size_t>(q_slots_cont, 64) : std::max((size_t)nw * seg_cap, q_slots_cont);
     // Multi-batch renders overlap the tail of batch k (continuation launch, resolve) with the body of batch k + 1
-    const bool overlap = n_batches > 1;
+    // (Not beside a regenerating level-0 launch: its waves hold every wave slot of the device for the whole launch, and
+    // a tail that has to squeeze in beside them stretches both -- C3 8 900 Msamples/s overlapped, 10 220 in order.)
+    const bool overlap = n_batches > 1 && !regen;
 
     int rc;
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
@@ -548,7 +566,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (overlap && hand_off && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
                                               (rc = c->csray[1].ensure(q_slots_cont))))
         return rc;
-    if ((rc = c->ovf_count.ensure(4))) return rc;
+    if ((rc = c->ovf_count.ensure(2 * kCountStride))) return rc;
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
             for (int k = 0; k < 4; ++k)
@@ -604,7 +622,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         a.lsamp = lsamp_b;
         // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
         if (overlap && batch >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[par], 0));
-        uint32_t* const d_count = c->ovf_count.p + par;
+        uint32_t* const d_count = c->ovf_count.p + kCountStride * par;   // [0] leftovers handed over, [64 ...] chunk counters of k_paths_regen
         // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
         // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
         for (uint32_t level = 0; level < (hand_off ? 2u : 1u); ++level) {
@@ -632,7 +650,16 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 a.ovf_in.q[k] = inject ? const_cast<float4*>(list->inject[k]) : (hand_off ? c->ovf[par][0][k].p : nullptr);
             }
             a.ovf_out_count = d_count;
-            if (level == 0 && hand_off) HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), ls));
+            a.chunk_counter = nullptr;
+            if (level == 0 && regen) {
+                a.chunk_counter = d_count + ptk::kRegenCounterStride;
+                a.export_below = c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;
+                g = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
+                // the first kRegenStatic16 / 16 of the chunks are dealt statically
+                const uint32_t nwr = g * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;
+                a.regen_static = (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
+            }
+            if (level == 0 && hand_off) HIP_TRY(hipMemsetAsync(d_count, 0, (regen ? kCountStride : 1u) * sizeof(uint32_t), ls));
             if (profile) {
                 if ((rc = ensure_events(c, 2 * (size_t)(launches + 1)))) return rc;
                 HIP_TRY(hipEventRecord(c->ev_pool[2 * launches], ls));

@@ -77,6 +77,11 @@ struct BounceArgs {
     // (src_mode = 1) takes its n_first paths from ovf_in instead of generating camera rays
     Queue ovf_in, ovf_out;
     uint32_t* ovf_out_count;
+    // non-null: level-0 launch in the regenerating form (k_paths_regen; scene in LDS, src_mode 0, no pixel list): the
+    // waves take the batch's 64-path chunks from this counter (zeroed before the launch) and export what is alive
+    // when it runs out
+    uint32_t* chunk_counter;
+    uint32_t regen_static;    // chunks dealt round-robin to the waves (a multiple of the launch's wave count); the rest by the counters
     uint32_t src_mode;        // 0: pass 0 generates camera rays, 1: pass 0 reads ovf_in
     uint32_t export_below;    // >= 1; 1 = never export (a wave runs until its segment is empty)
     uint32_t seg_cap;         // slots per segment (multiple of 64)
@@ -123,6 +128,13 @@ constexpr uint32_t kBvhStack = 24;         // traversal stack entries per lane, 
 // One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
 // (4 queue segments each).  _exact / _fast: the two arithmetic modes of pt_device.h
 // (PtRenderParams.exact_math).
+// occupancy k_paths_regen is compiled for (waves per SIMD = workgroups per CU): the host launches exactly that many
+#ifndef PT_REGEN_WAVES_DIFFUSE
+#define PT_REGEN_WAVES_DIFFUSE 6
+#endif
+constexpr uint32_t kRegenWavesDiffuse = PT_REGEN_WAVES_DIFFUSE, kRegenWavesGeneric = 5;
+// chunk counters of k_paths_regen: chunk_counter[c * kRegenCounterStride], c < kRegenCounters (256 bytes apart)
+constexpr uint32_t kRegenCounters = 8, kRegenCounterStride = 64;
 void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);
 void launch_paths_fast(const BounceArgs& a, uint32_t grid, hipStream_t st);
 

@@ -305,7 +305,8 @@ struct Vertex {
     f3 light_dir, ls_emission;
     float distance, ls_pdf;
     uint32_t w_bsdf1, w_bsdf2;   // the vertex's BSDF words of BLK_SURFACE (drawn together with the light words)
-    uint32_t w_lobe, w_rr;       // its BLK_CHOICE words, when vertex_begin had to draw that block (several lights)
+    uint32_t w_lobe;             // its lobe word of BLK_CHOICE, when vertex_begin had to draw that block (several lights)
+    uint32_t w_rr;               // its roulette word (made of the BLK_SURFACE bits u01() skips)
     int obj, light_obj;          // object hit (>= 0) and light picked: vertex_end can re-read their records (REMAT)
     bool hit_emitter;            // the path ray reached an emitter: vertex_end credits it (it needs the carry state)
     float emit_pdf_shape;        // ... with the light pdf of that point seen from the previous vertex (MIS, depth > 0)
@@ -414,12 +415,13 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
         uint32_t ds[4];
         philox4x32_10(sample, p.depth, BLK_SURFACE, 0u, kx, py, ds);
         v.w_bsdf1 = ds[2]; v.w_bsdf2 = ds[3];
+        v.w_rr = (ds[0] << 23) | ((ds[1] & 0x1FFu) << 14) | ((ds[2] & 0x1FFu) << 5);   // roulette word: the bits of the block u01() skips
         if (MIS && sc.n_lights > 0u) {
             uint32_t w_index = 0u;                                                // umulhi(u, 1) = 0: one light needs no draw
             if (sc.n_lights > 1u) {
                 uint32_t dc[4];
                 philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, kx, py, dc);
-                w_index = dc[0]; v.w_lobe = dc[1]; v.w_rr = dc[2];
+                w_index = dc[0]; v.w_lobe = dc[1];
             }
             f3 lp;
             sample_light_point<DIFFUSE>(sc, v.hit.point, w_index, ds[0], ds[1], lp, v.light_obj, v.ls_emission, v.ls_pdf);
@@ -467,12 +469,12 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
     bool alive = v.alive;
     if (alive) {
         // BLK_CHOICE: already drawn by vertex_begin when the scene has several lights; otherwise only a Mirror
-        // surface (lobe) or a vertex at depth >= MIN_DEPTH (roulette: below it rr = 1 > every uniform) reads it
+        // surface (lobe) reads it
         uint32_t w_lobe = v.w_lobe, w_rr = v.w_rr;
-        if (!(MIS && n_lights > 1u) && (v.m.tag == MAT_MIRROR || p.depth >= min_depth)) {
+        if (!(MIS && n_lights > 1u) && v.m.tag == MAT_MIRROR) {
             uint32_t dc[4];
             philox4x32_10(sample, p.depth, BLK_CHOICE, 0u, kx, py, dc);
-            w_lobe = dc[1]; w_rr = dc[2];
+            w_lobe = dc[1];
         }
         float eta_mat = v.m.tag == MAT_MIRROR ? v.m.ior : 1.0f;               // get_eta, material.rs:50 / mirror.rs:317
         float eta_here = v.hit.front_face ? pt_rcp(eta_mat) : eta_mat;         // rendering.rs:20-25
@@ -725,6 +727,170 @@ k_paths(BounceArgs a) {
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);   // level-0 launches only
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
+    }
+}
+
+// ------------------------------------------------------------------ the path kernel, regenerating form
+// Level-0 launch of a large batch over a scene in LDS (the throughput case: C1, C2, C3, C5).  k_paths keeps a path's
+// state in the queue and moves it through HBM once per vertex; here a path stays in its lane's registers from
+// its camera ray to its end, and a lane whose path has ended takes the next path of the batch on the spot
+// (regeneration; Novak et al. 2010).  So every lane of every wave carries a path until the batch runs out -- no
+// partially filled chunks, no queue traffic, no compaction -- and the only global accesses of the loop are the
+// 12 bytes a finished sample writes and the chunk counter.
+//   * Work: 64-path chunks of the batch (path id = s_local * np + pixel, as in k_paths).  The first regen_static chunks
+//     are dealt round-robin (chunk k -> wave k % nw), the rest is handed out by kRegenCounters global counters (counter c
+//     owns the chunks = c mod kRegenCounters; one returning atomic per chunk), so that the waves finish together: they
+//     do not run equally fast (a static deal of 15/16 of the chunks: 7.63 ms, of 3/4: 7.31).  ONE counter for every
+//     chunk saturates: the chip consumes ~150 chunks per microsecond and a single address takes ~85 atomics per
+//     microsecond (C2 12.3 instead of 8.0 ms).
+//   * Camera rays are generated for a whole chunk at a time, all 64 lanes busy, into a per-wave ring in LDS (direction +
+//     film position, 20 bytes; the origin is the camera's); a lane that needs a path pops the entry of its rank among
+//     the needy lanes.  Generating rays only for the lanes that need one would run the Philox + normalise code at
+//     ~20 % lane utilisation in every iteration.
+//   * End of the batch: when the counter is exhausted and a wave's ring is empty, its lanes run dry one by one; below
+//     export_below live paths the wave appends them to the overflow queue, as k_paths does, for the continuation launch.
+//   * The results do not depend on which lane traced which path: the RNG is addressed by (pixel, sample, depth), every
+//     sample has its own slot of lsamp, and the statistics are sums.
+// Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 77 VGPRs
+// (6 waves per SIMD), the generic one 91 (5).
+constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
+template <bool MIS, bool DIFFUSE>
+__global__ void __launch_bounds__(kBlock, DIFFUSE ? kRegenWavesDiffuse : kRegenWavesGeneric) k_paths_regen(BounceArgs a) {
+    extern __shared__ float4 lds[];
+    __shared__ float4 s_pool_d[kBlock / 64][kPool];      // (d.x, d.y, d.z, bits(tile_row << 16 | x))
+    __shared__ uint32_t s_pool_s[kBlock / 64][kPool];    // s_local << 16 (depth 0)
+    const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wib = threadIdx.x >> 6;
+    float4* const pool_d = s_pool_d[wib];
+    uint32_t* const pool_s = s_pool_s[wib];
+    const uint32_t n_first = a.n_first;
+    const uint32_t n_chunks = (n_first + 63u) >> 6;
+    const uint32_t W = a.film_w;
+    const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + wib, nw = gridDim.x * (kBlock / 64);
+    uint32_t st_next = wave;               // wave-uniform: next chunk of the static deal
+    uint32_t ctr = blockIdx.x % kRegenCounters, ctr_dry = 0;   // wave-uniform: counter in use, counters found used up
+    uint32_t pool_head = 0, pool_cnt = 0;  // wave-uniform: ring read position, entries
+    bool exhausted = false;                // wave-uniform: the batch has no more chunks
+    uint32_t wave_shadow = 0, wave_vertices = 0;
+    uint32_t dmax = 0;                     // per lane: deepest vertex of the paths this lane finished
+    PathState p = parked_state();
+    bool alive = false;
+
+    for (;;) {
+        // ---- keep at least one chunk of camera rays in the ring
+        while (!exhausted && pool_cnt < 64u) {
+            uint32_t chunk;
+            if (st_next < a.regen_static) {            // dealt round-robin, like pass 0 of k_paths
+                chunk = st_next; st_next += nw;
+            } else {
+                // the shared rest: chunk regen_static + ticket * kRegenCounters + c from counter c; a wave starts at the
+                // counter of its workgroup and moves on to the next one when that is used up
+                for (;;) {
+                    uint32_t got = 0;
+                    if (lane == 0u) got = atomicAdd(a.chunk_counter + ctr * kRegenCounterStride, 1u);
+                    chunk = a.regen_static + __builtin_amdgcn_readfirstlane(got) * kRegenCounters + ctr;
+                    if (chunk < n_chunks) break;
+                    ctr = ctr + 1u == kRegenCounters ? 0u : ctr + 1u;
+                    if (++ctr_dry == kRegenCounters) { exhausted = true; break; }
+                }
+                if (exhausted) break;
+            }
+            const uint32_t pid = chunk * 64u + lane;
+            const uint32_t valid = n_first - chunk * 64u < 64u ? n_first - chunk * 64u : 64u;
+            if (lane < valid) {
+                uint32_t s_local, pix, yl, px;
+                divmod_magic(pid, a.np, a.np_magic, s_local, pix);
+                divmod_magic(pix, W, a.film_w_magic, yl, px);
+                f3 o, d;
+                camera_ray(a.cam, a.s_base + s_local, px, image_row(a.tile, yl), o, d);
+                const uint32_t e = (pool_head + pool_cnt + lane) & (kPool - 1u);
+                pool_d[e] = make_float4(d.x, d.y, d.z, __uint_as_float((yl << 16) | px));
+                pool_s[e] = s_local << 16;
+            }
+            pool_cnt += valid;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lanes without a path take the ring's next entries, in lane order
+        {
+            const unsigned long long need = __ballot(!alive);
+            const uint32_t r = lane_rank(need);
+            if (!alive && r < pool_cnt) {
+                const uint32_t e = (pool_head + r) & (kPool - 1u);
+                const float4 q = pool_d[e];
+                const uint32_t sd = pool_s[e];
+                p.o = cam_o; p.d = mk(q.x, q.y, q.z);
+                const uint32_t xy = __float_as_uint(q.w);
+                p.yl = xy >> 16; p.px = xy & 0xFFFFu;
+                p.s_local = sd >> 16; p.depth = 0u;
+                p.beta = mk(1.f, 1.f, 1.f); p.L = mk(0.f, 0.f, 0.f);
+                p.pdf_prev = 0.0f; p.eta_in = 1.0f;
+                alive = true;
+            }
+            const uint32_t n_need = (uint32_t)__popcll(need);
+            const uint32_t n_take = n_need < pool_cnt ? n_need : pool_cnt;
+            pool_head += n_take; pool_cnt -= n_take;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+        // running dry (only once the batch is exhausted): hand the rest over
+        if (n_alive < a.export_below) break;           // export_below >= 1: a wave without paths ends
+
+        const bool active = alive;
+        const uint32_t kx = p.px, py = image_row(a.tile, p.yl);
+        const uint32_t sample = a.s_base + p.s_local;
+        wave_vertices += n_alive;
+
+        // ---- scan #1: closest hit of the path ray (rendering.rs:41)
+        int id; float t;
+        scan_closest<kModeLds>(sc, p.o, p.d, a.t_min, kInf, id, t);
+        Vertex v;
+        vertex_begin<MIS, DIFFUSE>(sc, p, active, id, t, sample, kx, py, v);
+
+        // ---- scan #2: visibility (rendering.rs:62-65)
+        bool visible = false;
+        if (MIS) {
+            const unsigned long long sm = __ballot(v.need_shadow);
+            if (sm != 0ull) {
+                f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
+                f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
+                int sid; float st;
+                scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                visible = v.need_shadow && sid < 0;
+                wave_shadow += (uint32_t)__popcll(sm);
+            }
+        }
+        alive = vertex_end<MIS, DIFFUSE, true>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
+        if (active && !alive) {
+            a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
+            dmax = p.depth > dmax ? p.depth : dmax;
+            p.o = parked_origin(); p.d = parked_dir();  // until the lane gets its next path (end of the batch: for good)
+        }
+    }
+
+    // ---- hand-over of the paths still alive (none unless the batch ran out under them)
+    {
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t n_left = (uint32_t)__popcll(mask);
+        if (n_left != 0u) {
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(a.ovf_out_count, n_left);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (alive) {
+                store_state(a.ovf_out, base + lane_rank(mask), p);
+                const uint32_t done = p.depth ? p.depth - 1u : 0u;   // deepest vertex it has been through (0: none yet)
+                dmax = done > dmax ? done : dmax;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off); dmax = w2 > dmax ? w2 : dmax; }
+    if (lane == 0u) {
+        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
+        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
+        if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
+        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
     }
 }
 
@@ -1045,6 +1211,13 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
         if (mode == kModeLds) launch_paths_mode<kModeLds, false, true>(a, grid, lds, st);
         else if (mode == kModeTiled) launch_paths_mode<kModeTiled, false, true>(a, grid, lds, st);
         else launch_paths_bvh<false, true>(a, grid, lds, st);
+        return;
+    }
+    if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen)
+        const bool mis = a.integrator == 0;
+        const dim3 g(grid), b(kBlock);
+        if (diffuse) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, true>), g, b, lds, st, a); }
+        else { if (mis) hipLaunchKernelGGL((k_paths_regen<true, false>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, false>), g, b, lds, st, a); }
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }

@@ -71,6 +71,8 @@ pub struct PtTuning {
     pub bvh_refill: u32,
     pub bvh_leaf: u32,
     pub cont_workgroups: u32,
+    pub level0_form: u32,
+    pub regen_workgroups: u32,
 }
 
 #[repr(C)]

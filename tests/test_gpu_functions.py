@@ -316,6 +316,53 @@ def test_tuning_knobs_do_not_change_the_film(pt, gpu_ctx):
         gpu_ctx.set_tuning()
 
 
+@pytest.mark.parametrize("scene,exact", [(2, 0), (2, 1), (1, 0), (1, 1)])
+def test_level0_forms_give_the_same_film(pt, gpu_ctx, scene, exact):
+    """The level-0 launch of a large batch has two forms: the queue form (k_paths: state through HBM once per vertex,
+    in-place compaction) and the regenerating form (k_paths_regen: a path stays in its lane's registers, a lane whose path
+    ends takes the batch's next one from the chunk counters).  Which lane traces which path -- and in the regenerating
+    form that depends on the timing of the atomics -- must not matter: both films, the vertex / shadow-ray counts and
+    the deepest vertex are identical, for the diffuse scene (regeneration is the default there) and for the reference
+    scene with its glass sphere, in both arithmetic modes, for several grid sizes of the regenerating launch (1
+    workgroup; fewer and more than the device holds at once)."""
+    gpu_ctx.upload(pt.builtin_scene(scene))
+    cam = pt.camera_new(width=1024, height=640)
+    prm = pt.default_params(spp=8, exact_math=exact)                  # 5.2 M paths: above the hand-off threshold
+    try:
+        gpu_ctx.set_tuning(level0_form=1)
+        ref, ref8 = gpu_ctx.render(cam, prm)
+        base = gpu_ctx.stats()
+        assert base.bounce_launches == 2
+        for form, wgs, eb in [(2, 0, 0), (2, 1, 0), (2, 333, 3), (2, 4000, 64), (0, 0, 0)]:
+            gpu_ctx.set_tuning(level0_form=form, regen_workgroups=wgs, export_below=eb)
+            lin, rgba = gpu_ctx.render(cam, prm)
+            st = gpu_ctx.stats()
+            assert torch_equal(lin, ref) and torch_equal(rgba, ref8), (form, wgs)
+            assert (st.vertices, st.shadow_rays, st.max_depth_reached) == (base.vertices, base.shadow_rays, base.max_depth_reached)
+    finally:
+        gpu_ctx.set_tuning()
+
+
+def test_regenerating_form_with_ragged_batches_and_bands(pt, gpu_ctx):
+    """Batches whose path count is not a multiple of 64, several of them (tails overlapped on the side stream), and a
+    row band: the regenerating form equals the queue form."""
+    gpu_ctx.upload(pt.builtin_scene(2))
+    cam = pt.camera_new(width=1023, height=517)
+    for kw in (dict(spp=19, max_paths_in_flight=1023 * 517 * 9), dict(spp=20, band_rows=100, band_index=1, band_count=2)):
+        prm = pt.default_params(**kw)
+        try:
+            gpu_ctx.set_tuning(level0_form=1)
+            ref, ref8 = gpu_ctx.render(cam, prm)
+            base = gpu_ctx.stats()
+            gpu_ctx.set_tuning(level0_form=2)
+            lin, rgba = gpu_ctx.render(cam, prm)
+            st = gpu_ctx.stats()
+        finally:
+            gpu_ctx.set_tuning()
+        assert torch_equal(lin, ref) and torch_equal(rgba, ref8), kw
+        assert (st.vertices, st.shadow_rays, st.max_depth_reached, st.batches) == (base.vertices, base.shadow_rays, base.max_depth_reached, base.batches)
+
+
 def torch_equal(a, b):
     import torch
     return torch.equal(a, b)

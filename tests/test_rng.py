@@ -45,3 +45,31 @@ def test_philox_uniformity_coarse(orc):
     assert abs(u.mean() - 0.5) < 0.01
     hist, _ = np.histogram(u, bins=16, range=(0, 1))
     assert hist.min() > 0.85 * len(u) / 16 and hist.max() < 1.15 * len(u) / 16
+
+
+def test_roulette_word_uses_only_bits_the_other_draws_skip(orc):
+    """The roulette uniform of a vertex is built from the low bits of its BLK_SURFACE words, which u01() of those words
+    never reads: changing the roulette bits leaves the four sample uniforms alone and vice versa; the uniform itself
+    is uniform and uncorrelated with them."""
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        ds = [int(v) for v in rng.integers(0, 2 ** 32, size=4, dtype=np.uint64)]
+        w = orc.rr_word(ds)
+        assert w == ((ds[0] << 23) & 0xFFFFFFFF) | ((ds[1] & 0x1FF) << 14) | ((ds[2] & 0x1FF) << 5)
+        top = [(v >> 9) << 9 for v in ds]                    # what u01 reads
+        low = [v & 0x1FF for v in ds]
+        other = [t | int(l) for t, l in zip(top, rng.integers(0, 512, size=4))]
+        assert [orc.u01(a) for a in other] == [orc.u01(a) for a in ds]             # samples do not see the low bits
+        swapped = [int(t) << 9 | l for t, l in zip(rng.integers(0, 2 ** 23, size=4), low)]
+        assert orc.u01(orc.rr_word(swapped)) == orc.u01(w)                           # roulette does not see the top bits
+    us, rs = [], []
+    for s_ in range(6000):
+        ds = orc.philox([s_, 2, 0, 0], [12, 34])
+        rs.append(orc.u01(orc.rr_word(ds)))
+        us.append([orc.u01(v) for v in ds])
+    rs, us = np.array(rs), np.array(us)
+    assert abs(rs.mean() - 0.5) < 0.012
+    hist, _ = np.histogram(rs, bins=16, range=(0, 1))
+    assert hist.min() > 0.8 * len(rs) / 16 and hist.max() < 1.2 * len(rs) / 16
+    for k in range(4):
+        assert abs(np.corrcoef(rs, us[:, k])[0, 1]) < 0.04
