@@ -17,7 +17,7 @@ its rows are dealt to the ranks in interleaved bands and ONE gather per step ass
 frame on rank 0.  `--workload c5` is the configuration built for 8 GPUs (3840x2160x1024 spp).
 
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the level-0 launch
-of k_paths) against what bounds it: the f32 VALU (bound "valu": there is no dense contraction
+of a sample batch: k_paths_regen for the default workload) against what bounds it: the f32 VALU (bound "valu": there is no dense contraction
 on this path, so the schema's "mfma" slot does not apply; the peak is the same 157.3 TFLOP/s
 f32 rate).  achieved = ALGORITHMIC flops of SURVEY 8(d) -- F_isect per primitive test of every
 scan the launch ran (23 per sphere, 51 per triangle) + 200 per path vertex -- divided by the
@@ -271,7 +271,13 @@ def main():
         if args.accel == 1 or (args.accel == 2 and len(objs) > 512):
             kernel = "k_paths_bvh<MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
         elif len(objs) <= 128:
-            kernel = "k_paths<kModeLds, MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
+            # large batches over a scene in LDS: the regenerating form where the library takes it (pt_api.cpp: diffuse scenes
+            # by default, PtTuning.level0_form), the queue form otherwise
+            big = acc["samples"] / max(acc["p_launches"], 1) > (1 << 22)
+            if big and (args.level0_form == 2 or (args.level0_form == 0 and diffuse)):
+                kernel = "k_paths_regen<MIS, %s>" % ("DIFFUSE" if diffuse else "generic")
+            else:
+                kernel = "k_paths<kModeLds, MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
         else:
             kernel = "k_paths<kModeTiled, MIS, OVF=false>"
         roof = {
