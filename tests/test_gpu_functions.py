@@ -269,13 +269,14 @@ def test_ray_color_on_arbitrary_rays(pt, orc, gpu_ctx, integrator):
 
 
 # ---------------------------------------------------------------- the entry is asynchronous / graph-capturable
-def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx):
+@pytest.mark.parametrize("scene", [1, 2])     # 1: queue-form level-0 launch (GGX surface), 2: regenerating form (chunk counters reset by a memset node)
+def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene):
     """pt_render_device enqueues and returns: no host synchronisation, no allocation once its buffers exist.  So it can
     be captured into a hipGraph (torch.cuda.CUDAGraph on the stream the context renders on) and replayed; the film of
     a replay is the film of a direct call.  1024 x 1024 x 8 spp = 8.4 M paths: large enough for the tail hand-off
     (level-0 launch + continuation launch that reads its path count on the device)."""
     import torch
-    objs = pt.builtin_scene(1)
+    objs = pt.builtin_scene(scene)
     gpu_ctx.upload(objs)
     cam = pt.camera_new(width=1024, height=1024)
     prm = pt.default_params(spp=8)
