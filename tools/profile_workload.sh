@@ -6,7 +6,7 @@
 set -e
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
 python3 $ARGS > $OUT/bench_plain.json
