@@ -55,6 +55,9 @@ template <class T> struct DevBuf {
 };
 
 constexpr uint64_t kDefaultMaxPaths = 1ull << 26;
+// ... where the level-0 launch keeps its paths in registers (k_paths_regen) a path in flight costs 12 bytes of sample buffer
+// instead of 76, and every batch ends in a ~0.3 ms tail: larger batches (C3: 16 instead of 64)
+constexpr uint64_t kDefaultMaxPathsRegen = 1ull << 28;
 // Default number of workgroups.  What matters is that the queue segments of the RESIDENT waves fit the 256 MiB
 // Infinity Cache (and that the dispatcher has enough workgroups to balance the end of the launch; much smaller
 // segments pay more low-occupancy tail passes).  Scene in LDS, 6 waves/SIMD = 6144 resident waves: ~672 paths
@@ -500,7 +503,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (!d_linear) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer is null");
     if (!list && (cam->width > 65535u || tile_rows > 65535u))   // (tile row, x) share one word of the path state
         return fail(PT_ERR_UNSUPPORTED, "tile %ux%llu: width and tile rows must be < 65536", cam->width, (unsigned long long)tile_rows);
-    uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : kDefaultMaxPaths;
+    // scene / job that can take the regenerating level-0 kernel (decided below, once the batch size is known)
+    const bool regen_scene = (c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && c->view.diffuse_only)) && !list && !prm->accel &&
+                             c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
+    uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : (regen_scene ? kDefaultMaxPathsRegen : kDefaultMaxPaths);
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)
         return fail(PT_ERR_UNSUPPORTED, "tile of %llu pixels exceeds max_paths_in_flight %llu; use more bands",
@@ -534,8 +540,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // path ends takes the next one of the batch; grid = the waves the device holds at once (k_paths_regen).
     // (Scenes with GGX / OrenNayar surfaces keep the queue form unless asked: paths of every depth and material share a
     // wave there, and the divergence costs what the form saves -- C1 12.40 vs 12.21 ms.)
-    const bool regen = (c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && c->view.diffuse_only)) && hand_off && !list &&
-                       !prm->accel && c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
+    const bool regen = regen_scene && hand_off;
     const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups :
                                 c->n_cus * (c->view.diffuse_only ? ptk::kRegenWavesDiffuse : ptk::kRegenWavesGeneric));
     const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
