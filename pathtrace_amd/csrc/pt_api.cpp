@@ -72,9 +72,13 @@ constexpr uint32_t kMinGrid = 256 * 8;         // level-0 launches: at least thi
 // Measured on C2 / C1, ms of the continuation launch: 96 workgroups 1.75 / 5.0, 192 0.98 / 2.7, 384 0.60 / 1.6,
 // 768 0.44 / 1.16, 1024 0.46, 1536 0.51 / 1.19, 3072 0.69 (round 1: 6144 -> +0.8).
 constexpr uint32_t kContGrid = 1024;
+#ifndef PT_REGEN_EXPORT
+#define PT_REGEN_EXPORT 1
+#endif
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
 constexpr uint32_t kRegenStatic16 = 4;         // k_paths_regen: sixteenths of a batch's chunks dealt round-robin, the rest by the counters
-constexpr uint32_t kRegenExportBelow = 16;     // ... and its waves hand over once the batch is used up and fewer paths than this are alive
+constexpr uint32_t kRegenExportBelow = PT_REGEN_EXPORT;  // ... and its waves hand over once the batch is used up and fewer paths than this are alive
+                                               // (1: they run dry themselves and no continuation launch follows)
 constexpr uint32_t kExportSmall = 64;          // a wave hands its segment over when fewer paths than this are left
                                                // (measured 32 ... 256: no difference beyond noise on C1 and C2)
 // Tail hand-off: in launches of more than kExportMinPaths paths a wave whose segment falls below one chunk
@@ -630,7 +634,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         uint32_t* const d_count = c->ovf_count.p + kCountStride * par;   // [0] leftovers handed over, [64 ...] chunk counters of k_paths_regen
         // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
         // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
-        for (uint32_t level = 0; level < (hand_off ? 2u : 1u); ++level) {
+        // (a regenerating launch whose waves run dry themselves leaves nothing for a continuation launch)
+        const uint32_t regen_export = c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;
+        const uint32_t n_levels = hand_off && !(regen && regen_export <= 1u) ? 2u : 1u;
+        for (uint32_t level = 0; level < n_levels; ++level) {
             hipStream_t ls = level == 0 ? st : side;
             const bool own = overlap && level > 0;       // continuation launch of an overlapped batch: its own queue
             uint32_t g = grid;
@@ -658,7 +665,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             a.chunk_counter = nullptr;
             if (level == 0 && regen) {
                 a.chunk_counter = d_count + ptk::kRegenCounterStride;
-                a.export_below = c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;
+                a.export_below = regen_export;
                 g = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
                 // the first kRegenStatic16 / 16 of the chunks are dealt statically
                 const uint32_t nwr = g * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;

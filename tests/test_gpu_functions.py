@@ -282,7 +282,7 @@ def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene):
     prm = pt.default_params(spp=8)
     ref, ref8 = gpu_ctx.render(cam, prm)                       # also creates every buffer of this size
     st = gpu_ctx.stats()
-    assert st.bounce_launches == 2 and st.batches == 1
+    assert st.bounce_launches == (2 if scene == 1 else 1) and st.batches == 1     # regenerating waves run dry themselves
     dev = torch.device("cuda", 0)
     lin = torch.zeros_like(ref); rgba = torch.zeros_like(ref8)
     stream = torch.cuda.Stream(dev)

@@ -1,7 +1,7 @@
 """Time of one rank's share of the C2 job at N = 1, 2, 4, 8 on ONE GPU: the rank-0 row bands of bench.py's strong-scaling
 split (interleaved 16-row bands), device-resident, HIP events around `reps` renders.  The per-rank fixed cost (tail,
 launch gaps) is what limits strong scaling; the RCCL gather is not in this number.
-    python tools/tile_scaling.py [band_rows]"""
+    python tools/tile_scaling.py [band_rows [export_below]]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,7 @@ import pathtrace_amd as pt
 
 band = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ctx = pt.Context(0); ctx.upload(pt.builtin_scene(2))
+ctx.set_tuning(export_below=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 cam = pt.camera_new(width=1024, height=1024)
 dev = torch.device("cuda", 0)
 for n in (1, 2, 4, 8):
