@@ -75,6 +75,7 @@ constexpr uint32_t kContGrid = 1024;
 #ifndef PT_REGEN_EXPORT
 #define PT_REGEN_EXPORT 1
 #endif
+constexpr uint32_t kStatsWords = 16;            // 8 x u64 render statistics at the front of the counter buffer
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
 constexpr uint32_t kRegenStatic16 = 4;         // k_paths_regen: sixteenths of a batch's chunks dealt round-robin, the rest by the counters
 constexpr uint32_t kRegenExportBelow = PT_REGEN_EXPORT;  // ... and its waves hand over once the batch is used up and fewer paths than this are alive
@@ -144,7 +145,6 @@ struct PtContext {
     hipEvent_t ev_l0[2] = {nullptr, nullptr}, ev_resolved[2] = {nullptr, nullptr};
     uint32_t* h_ovf = nullptr;        // pinned read-back of one counter
     DevBuf<ptk::Rgb> lsamp;
-    DevBuf<unsigned long long> dstats;
     DevBuf<double> film;
     DevBuf<float> host_lin;       // device staging of pt_render_host
     DevBuf<uint8_t> host_rgba;
@@ -347,7 +347,7 @@ int pt_context_destroy(PtContext* c) {
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     c->ovf_count.release();
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
-    c->lsamp.release(); c->dstats.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
+    c->lsamp.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
     c->pixel_list.release(); c->fn_in.release(); c->fn_out.release(); c->fn_words.release();
     for (auto& b : c->inject) b.release();
     if (c->h_dstats) (void)hipHostFree(c->h_dstats);
@@ -575,16 +575,16 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (overlap && hand_off && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
                                               (rc = c->csray[1].ensure(q_slots_cont))))
         return rc;
-    if ((rc = c->ovf_count.ensure(2 * kCountStride))) return rc;
+    if ((rc = c->ovf_count.ensure(kStatsWords + 2 * kCountStride))) return rc;   // [render statistics | counters of batch parity 0 | parity 1]
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
             for (int k = 0; k < 4; ++k)
                 if ((rc = c->ovf[par][0][k].ensure(ovf_slots))) return rc;
-    if ((rc = c->dstats.ensure(8))) return rc;
     if ((n_batches > 1 || fs.load || fs.store) && (rc = c->film.ensure((size_t)np * 3))) return rc;
 
     ptk::BounceArgs a{};
-    a.stats = c->dstats.p;
+    unsigned long long* const d_stats = reinterpret_cast<unsigned long long*>(c->ovf_count.p);   // hipMalloc alignment: fine for u64
+    a.stats = d_stats;
     if (!list) {   // tile row -> image row without a table (ptk::TileMap)
         const uint32_t br = prm->band_rows ? prm->band_rows : cam->height;
         a.tile.band_rows = br;
@@ -612,7 +612,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     a.bvh_leaf = c->tuning.bvh_leaf ? c->tuning.bvh_leaf : ptk::kLeafBatch;
 
     const bool profile = prm->profile != 0;
-    HIP_TRY(hipMemsetAsync(c->dstats.p, 0, 8 * sizeof(unsigned long long), st));
+    // statistics and the first batch's counters sit side by side: one fill for both
+    const size_t first_counters = hand_off ? (regen ? kCountStride : 1u) : 0u;
+    HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, (kStatsWords + first_counters) * sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(c->ev_begin, st));
     uint32_t launches = 0;
     c->primary_events.clear();
@@ -631,7 +633,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         a.lsamp = lsamp_b;
         // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
         if (overlap && batch >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[par], 0));
-        uint32_t* const d_count = c->ovf_count.p + kCountStride * par;   // [0] leftovers handed over, [64 ...] chunk counters of k_paths_regen
+        uint32_t* const d_count = c->ovf_count.p + kStatsWords + kCountStride * par;   // [0] leftovers handed over, [64 ...] chunk counters of k_paths_regen
         // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
         // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
         // (a regenerating launch whose waves run dry themselves leaves nothing for a continuation launch)
@@ -671,7 +673,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 const uint32_t nwr = g * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;
                 a.regen_static = (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
             }
-            if (level == 0 && hand_off) HIP_TRY(hipMemsetAsync(d_count, 0, (regen ? kCountStride : 1u) * sizeof(uint32_t), ls));
+            if (level == 0 && hand_off && batch > 0) HIP_TRY(hipMemsetAsync(d_count, 0, (regen ? kCountStride : 1u) * sizeof(uint32_t), ls));
             if (profile) {
                 if ((rc = ensure_events(c, 2 * (size_t)(launches + 1)))) return rc;
                 HIP_TRY(hipEventRecord(c->ev_pool[2 * launches], ls));
@@ -704,7 +706,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (overlap)        // the caller's stream is complete when the last resolve is (the side stream is in order)
         HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
     HIP_TRY(hipEventRecord(c->ev_end, st));
-    HIP_TRY(hipMemcpyAsync(c->h_dstats, c->dstats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_dstats, d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     c->stats.samples = (uint64_t)np * spp;
     c->stats.bounce_launches = launches;
     c->stats.batches = n_batches;
