@@ -557,7 +557,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const size_t q_slots = regen ? std::max<size_t>(q_slots_cont, 64) : std::max((size_t)nw * seg_cap, q_slots_cont);
     // Multi-batch renders overlap the tail of batch k (continuation launch, resolve) with the body of batch k + 1
     // (Not beside a regenerating level-0 launch: its waves hold every wave slot of the device for the whole launch, and
-    // a tail that has to squeeze in beside them stretches both -- C3 8 900 Msamples/s overlapped, 10 220 in order.)
+    // a tail that has to squeeze in beside them stretches both -- C3 8 900 Msamples/s overlapped, 10 220 in order; with
+    // only the 23-VGPR resolve kernel beside it, which would fit: 8 590 against 10 780.)
+    const uint32_t regen_export = c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;
     const bool overlap = n_batches > 1 && !regen;
 
     int rc;
@@ -637,7 +639,6 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
         // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
         // (a regenerating launch whose waves run dry themselves leaves nothing for a continuation launch)
-        const uint32_t regen_export = c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;
         const uint32_t n_levels = hand_off && !(regen && regen_export <= 1u) ? 2u : 1u;
         for (uint32_t level = 0; level < n_levels; ++level) {
             hipStream_t ls = level == 0 ? st : side;
