@@ -259,6 +259,18 @@ int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* 
 int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam, const PtObject* objs,
                     uint32_t n_objs, const PtRenderParams* params, float* out_linear_rgb, uint8_t* out_rgba8);
 
+/* The two kernels pt_multi_* runs around its ncclGather, for hosts that bring their own collective (one process per GPU:
+ * pathtrace_amd/dist.py over torch.distributed / RCCL, an MPI host, ...).  Both work on DEVICE memory of the calling
+ * thread's current HIP device and are enqueued on hip_stream (a hipStream_t; NULL = that device's default stream).
+ *   pt_film_pack:   a rank's tile (d_linear_rgb: n_pixels * 3 floats, d_rgba8: n_pixels * 4 bytes or NULL) ->
+ *                   d_packed, 16 bytes per pixel (12 B linear RGB + 4 B RGBA8): both film planes in ONE gather.
+ *   pt_film_unpack: the gathered tiles (rank g's tile, padded to max_rows rows, at d_gathered + g * max_rows * width *
+ *                   16 bytes) -> the frame in image order (d_linear_rgb: width * height * 3 floats, d_rgba8 or NULL),
+ *                   for the interleaved bands of PtRenderParams (band b belongs to rank b % n_ranks).               */
+int pt_film_pack(void* hip_stream, const float* d_linear_rgb, const uint8_t* d_rgba8, uint32_t n_pixels, void* d_packed);
+int pt_film_unpack(void* hip_stream, const void* d_gathered, uint32_t width, uint32_t height, uint32_t band_rows,
+                   uint32_t n_ranks, uint32_t max_rows, float* d_linear_rgb, uint8_t* d_rgba8);
+
 /* Debug / parity entry: the frame of an n_virtual-device render on ONE context (tiles rendered one after another,
  * device-to-device copies where pt_multi_* runs ncclGather): partition, pack and unpack for any n on a one-GPU box. */
 int pt_debug_multi_emulate(PtContext* ctx, uint32_t n_virtual, const PtCamera* cam, const PtRenderParams* params,

@@ -131,6 +131,8 @@ SYMBOLS = {
     "pt_multi_sync": (C.c_int, [C.c_void_p]),
     "pt_multi_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
     "pt_multi_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_film_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "pt_film_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pt_debug_multi_emulate": (C.c_int, [C.c_void_p, C.c_uint32, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_render_multi": (C.c_int, [_P(C.c_int), C.c_uint32, _P(PtCamera), _P(PtObject), C.c_uint32, _P(PtRenderParams),
                                   C.c_void_p, C.c_void_p]),

@@ -310,4 +310,31 @@ int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam,
     return pt_multi_render_host(g_multi, cam, prm, out_linear, out_rgba);
 }
 
+// The kernels around the gather, for hosts with their own collective (pathtrace_amd/dist.py).
+int pt_film_pack(void* hip_stream, const float* d_linear, const uint8_t* d_rgba, uint32_t n_pixels, void* d_packed) {
+    if (n_pixels == 0) return PT_OK;
+    if (!d_linear || !d_packed) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_film_pack: null buffer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return pt_internal_fail(PT_ERR_NO_DEVICE, "pt_film_pack: no HIP device");
+    ptk::launch_film_pack(d_linear, d_rgba, n_pixels, d_packed, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+int pt_film_unpack(void* hip_stream, const void* d_gathered, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t n_ranks,
+                   uint32_t max_rows, float* d_linear, uint8_t* d_rgba) {
+    if ((uint64_t)width * height == 0) return PT_OK;
+    if (!d_gathered || !d_linear) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_film_unpack: null buffer");
+    if ((uint64_t)width * height > 0xFFFFFFFFull) return pt_internal_fail(PT_ERR_UNSUPPORTED, "pt_film_unpack: more than 2^32 pixels");
+    if (n_ranks == 0) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_film_unpack: n_ranks is 0");
+    if (band_rows == 0) band_rows = height;                      // one band = the whole image (PtRenderParams convention)
+    // every image row must lie inside its rank's padded tile (rank 0 owns the largest one)
+    if (max_rows < pt_tile_rows(height, band_rows, 0, n_ranks))
+        return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_film_unpack: max_rows %u is smaller than the largest tile", max_rows);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return pt_internal_fail(PT_ERR_NO_DEVICE, "pt_film_unpack: no HIP device");
+    ptk::launch_film_unpack(d_gathered, width, height, band_rows, n_ranks, max_rows, d_linear, d_rgba, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
 }  // extern "C"

@@ -14,6 +14,22 @@ import torch.distributed as dist
 from .api import tile_row_indices
 
 
+def _lib():
+    from . import _lib as L
+    return L.lib()
+
+
+def _check(rc):
+    from . import _lib as L
+    L.check(rc)
+
+
+def _stream_ptr(device):
+    """torch's current stream on `device` as the hipStream_t the C ABI takes (0 = the default stream)."""
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
 def default_band_rows(height, world_size, target_bands_per_rank=8):
     """Band height giving every rank about `target_bands_per_rank` interleaved bands."""
     return max(1, height // max(1, world_size * target_bands_per_rank))
@@ -47,8 +63,9 @@ def gather_tiles(tile, height, band_rows, rank, world_size, group=None, dst=0):
 class FilmGather:
     """The per-frame exchange with everything that does not change from frame to frame done once: row
     partition, padded send tile, receive buffer and the row permutation that puts the gathered band rows in
-    image order.  Per frame: two pack copies, ONE dist.gather, one index_select, two unpack copies -- no Python
-    loop over rows, no host-to-device copy.  start()/finish() split the exchange so that the gather of frame k
+    image order.  Per frame on a GPU: the library's pack kernel (pt_film_pack), ONE dist.gather, the library's unpack
+    kernel (pt_film_unpack) -- the kernels pt_multi_* runs around its ncclGather; on the CPU (gloo tests): two pack
+    copies, the gather, one index_select, two unpack copies.  No Python loop over rows, no host-to-device copy.  start()/finish() split the exchange so that the gather of frame k
     overlaps the rendering of frame k + 1 (bench.py); calling the object does both at once.
 
     Both film planes travel together: the f32 linear plane [rows, W, 3] and the RGBA8 plane [rows, W, 4] are
@@ -57,6 +74,7 @@ class FilmGather:
     def __init__(self, height, width, band_rows, rank, world_size, device, group=None, dst=0, always_collective=False):
         rows = [tile_row_indices(height, band_rows, g, world_size) for g in range(world_size)]
         self.height, self.width, self.rank, self.world, self.group, self.dst = height, width, rank, world_size, group, dst
+        self.band_rows = band_rows
         self.my_rows = len(rows[rank])
         self.max_rows = max(len(r) for r in rows)
         self.send = torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device)
@@ -80,10 +98,7 @@ class FilmGather:
         flight is completed first (its frame is then available from finish())."""
         if self._work is not None or self._pending:
             self._last = self.finish()
-        n, w = self.my_rows, self.width
-        assert lin.shape[0] == n and rgba.shape[0] == n, (lin.shape, rgba.shape, n)
-        self.send[:n, :, :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(n, w, 12)
-        self.send[:n, :, 12:] = rgba
+        self._pack(lin, rgba)
         if self._collective:
             self._work = dist.gather(self.send, gather_list=self.bufs, dst=self.dst, group=self.group, async_op=True)
         self._pending = True
@@ -100,8 +115,33 @@ class FilmGather:
         self._pending = False
         if self.rank != self.dst:
             return None, None
+        return self._unpack(self.recv.view(self.world * self.max_rows, self.width, 16) if self._collective else self.send)
+
+    def _pack(self, lin, rgba):
+        """This rank's tile -> self.send (16 bytes per pixel)."""
+        n, w = self.my_rows, self.width
+        assert lin.shape[0] == n and rgba.shape[0] == n, (lin.shape, rgba.shape, n)
+        if self.send.is_cuda:
+            # the library's pack kernel (pt_film_pack: 16-byte stores) on torch's current stream, where the gather is ordered
+            lin, rgba = lin.contiguous(), rgba.contiguous()
+            assert lin.dtype == torch.float32 and rgba.dtype == torch.uint8
+            with torch.cuda.device(self.send.device):
+                _check(_lib().pt_film_pack(_stream_ptr(self.send.device), lin.data_ptr(), rgba.data_ptr(), n * w, self.send.data_ptr()))
+        else:
+            self.send[:n, :, :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(n, w, 12)
+            self.send[:n, :, 12:] = rgba
+
+    def _unpack(self, src):
+        """Gathered padded tiles [world * max_rows, W, 16] -> (linear [H, W, 3] f32, rgba [H, W, 4] u8) in image order."""
         w = self.width
-        src = self.recv.view(self.world * self.max_rows, w, 16) if self._collective else self.send
+        if src.is_cuda:
+            # the library's unpack kernel (pt_film_unpack): gathered padded tiles -> both film planes in image order
+            lin_full = torch.empty((self.height, w, 3), dtype=torch.float32, device=src.device)
+            rgba_full = torch.empty((self.height, w, 4), dtype=torch.uint8, device=src.device)
+            with torch.cuda.device(src.device):
+                _check(_lib().pt_film_unpack(_stream_ptr(src.device), src.data_ptr(), w, self.height, self.band_rows, self.world,
+                                             self.max_rows, lin_full.data_ptr(), rgba_full.data_ptr()))
+            return lin_full, rgba_full
         frame = src.index_select(0, self.perm)
         lin_full = frame[..., :12].contiguous().reshape(-1).view(torch.float32).reshape(self.height, w, 3)
         return lin_full, frame[..., 12:].contiguous()

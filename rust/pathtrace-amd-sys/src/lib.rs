@@ -136,6 +136,8 @@ extern "C" {
     pub fn pt_multi_get_stats(m: *mut PtMulti, out: *mut PtStats) -> c_int;
     pub fn pt_multi_render_host(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render_multi(devices: *const c_int, n_devices: u32, cam: *const PtCamera, objs: *const PtObject, n_objs: u32, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
+    pub fn pt_film_pack(hip_stream: *mut c_void, d_linear_rgb: *const f32, d_rgba8: *const u8, n_pixels: u32, d_packed: *mut c_void) -> c_int;
+    pub fn pt_film_unpack(hip_stream: *mut c_void, d_gathered: *const c_void, width: u32, height: u32, band_rows: u32, n_ranks: u32, max_rows: u32, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
     pub fn pt_debug_multi_emulate(ctx: *mut PtContext, n_virtual: u32, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render_pixels(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, xy: *const u32, n: u32, out_linear_rgb: *mut f32, out_rgba8: *mut u8, out_samples: *mut f32) -> c_int;
     pub fn pt_ray_color(ctx: *mut PtContext, params: *const PtRenderParams, rays: *const f64, xy: *const u32, n: u32, out_rgb: *mut f32) -> c_int;

@@ -429,3 +429,35 @@ def test_large_pixel_list_takes_the_tail_hand_off(pt, gpu_ctx):
     st = gpu_ctx.stats()
     assert st.bounce_launches == 2 and st.samples == 512 * 512 * 24
     assert np.array_equal(lin, full.cpu().numpy()[xy[:, 1], xy[:, 0]]) and np.array_equal(rgba, full8.cpu().numpy()[xy[:, 1], xy[:, 0]])
+
+
+# ---------------------------------------------------------------- the per-process form's film exchange on the GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,band,n", [(23, 20, 3, 3), (16, 8, 16, 2), (9, 5, 1, 4), (128, 64, 16, 8), (37, 33, 4, 1)])
+def test_film_pack_and_unpack_kernels_of_the_per_process_form(pt, H, W, band, n):
+    """pathtrace_amd/dist.py (one process per GPU, gather by torch.distributed) packs and unpacks the film with the
+    library's kernels (pt_film_pack / pt_film_unpack, the ones pt_multi_* runs around its ncclGather) when the tiles are
+    on a GPU.  Here the ranks' tiles are packed one after another on this GPU, laid out as the gather would deliver them,
+    and unpacked: both planes come back bit for bit, for ragged bands, ranks without a band and a single rank -- and
+    equal what the CPU form of the same class (the one the gloo tests run) produces."""
+    import torch
+    from pathtrace_amd.dist import FilmGather
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(H * 131 + W)
+    lin = torch.randn((H, W, 3), generator=g, dtype=torch.float32)
+    lin[0, 0, 0] = float("inf"); lin[H - 1, W - 1, 2] = -0.0                   # bit patterns, not values
+    rgba = torch.randint(0, 256, (H, W, 4), generator=g, dtype=torch.uint8)
+    rows = [pt.tile_row_indices(H, band, r, n) for r in range(n)]
+    for device in (dev, torch.device("cpu")):
+        ranks = [FilmGather(H, W, band, r, n, device) for r in range(n)]
+        root = ranks[0]
+        recv = torch.zeros((n, root.max_rows, W, 16), dtype=torch.uint8, device=device)
+        for r in range(n):
+            idx = torch.as_tensor(rows[r], dtype=torch.int64)
+            ranks[r]._pack(lin[idx].to(device), rgba[idx].to(device))
+            recv[r] = ranks[r].send
+        out_lin, out_rgba = root._unpack(recv.view(n * root.max_rows, W, 16))
+        assert torch.equal(out_lin.cpu().view(torch.int32), lin.view(torch.int32)), str(device)
+        assert torch.equal(out_rgba.cpu(), rgba), str(device)
+    with pytest.raises(pt._lib.PtError, match="max_rows"):
+        pt._lib.check(pt._lib.lib().pt_film_unpack(None, recv.data_ptr(), W, H, band, n, 0, out_lin.data_ptr(), None))
