@@ -281,8 +281,11 @@ def main():
         else:
             kernel = "k_paths<kModeTiled, MIS, OVF=false>"
         roof = {
-            "kernel": kernel + ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
-                      "over their sparse tails), rank 0.  Bound by f32 VALU issue (no contraction on this path: the "
+            "kernel": kernel + (": the one path-kernel launch of a sample batch (camera rays + every bounce of every path; a lane "
+                                "whose path ends takes the batch's next one)" if kernel.startswith("k_paths_regen") else
+                                ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
+                                "over their sparse tails)") +
+                      ", rank 0.  Bound by f32 VALU issue (no contraction on this path: the "
                       "schema's mfma slot does not apply; same 157.3 TFLOP/s f32 peak)",
             "bound": "valu",
             "achieved": round(achieved_tf, 2),
