@@ -731,28 +731,29 @@ k_paths(BounceArgs a) {
 }
 
 // ------------------------------------------------------------------ the path kernel, regenerating form
-// Level-0 launch of a large batch over a scene in LDS (the throughput case: C1, C2, C3, C5).  k_paths keeps a path's
+// Level-0 launch of a large batch over a diffuse scene in LDS (the throughput case: C2, C3, C5).  k_paths keeps a path's
 // state in the queue and moves it through HBM once per vertex; here a path stays in its lane's registers from
 // its camera ray to its end, and a lane whose path has ended takes the next path of the batch on the spot
 // (regeneration; Novak et al. 2010).  So every lane of every wave carries a path until the batch runs out -- no
 // partially filled chunks, no queue traffic, no compaction -- and the only global accesses of the loop are the
-// 12 bytes a finished sample writes and the chunk counter.
+// 12 bytes a finished sample writes and the chunk counters.
 //   * Work: 64-path chunks of the batch (path id = s_local * np + pixel, as in k_paths).  The first regen_static chunks
 //     are dealt round-robin (chunk k -> wave k % nw), the rest is handed out by kRegenCounters global counters (counter c
 //     owns the chunks = c mod kRegenCounters; one returning atomic per chunk), so that the waves finish together: they
-//     do not run equally fast (a static deal of 15/16 of the chunks: 7.63 ms, of 3/4: 7.31).  ONE counter for every
-//     chunk saturates: the chip consumes ~150 chunks per microsecond and a single address takes ~85 atomics per
+//     do not run equally fast -- a SIMD serves its oldest wave first -- (a static deal of 15/16 of the chunks: 7.63 ms,
+//     of 1/2: 6.87, of 1/4: 6.36).  ONE counter for every chunk saturates: the chip consumes ~150 chunks per microsecond and a single address takes ~85 atomics per
 //     microsecond (C2 12.3 instead of 8.0 ms).
 //   * Camera rays are generated for a whole chunk at a time, all 64 lanes busy, into a per-wave ring in LDS (direction +
 //     film position, 20 bytes; the origin is the camera's); a lane that needs a path pops the entry of its rank among
 //     the needy lanes.  Generating rays only for the lanes that need one would run the Philox + normalise code at
 //     ~20 % lane utilisation in every iteration.
-//   * End of the batch: when the counter is exhausted and a wave's ring is empty, its lanes run dry one by one; below
-//     export_below live paths the wave appends them to the overflow queue, as k_paths does, for the continuation launch.
+//   * End of the batch: when the counters are used up and a wave's ring is empty, its lanes run dry one by one.  By
+//     default (export_below = 1) the wave ends with its last path and no continuation launch follows; with a larger
+//     threshold it appends what is alive below it to the overflow queue, as k_paths does (measured: not faster).
 //   * The results do not depend on which lane traced which path: the RNG is addressed by (pixel, sample, depth), every
 //     sample has its own slot of lsamp, and the statistics are sums.
-// Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 77 VGPRs
-// (6 waves per SIMD), the generic one 91 (5).
+// Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 79 VGPRs
+// (6 waves per SIMD), the generic one 93 (5; reached only with PtTuning.level0_form = 2).
 constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
 template <bool MIS, bool DIFFUSE>
 __global__ void __launch_bounds__(kBlock, DIFFUSE ? kRegenWavesDiffuse : kRegenWavesGeneric) k_paths_regen(BounceArgs a) {
