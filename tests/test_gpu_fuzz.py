@@ -79,3 +79,43 @@ def test_random_scene_matches_f32_oracle(pt, orc, gpu_ctx, seed):
         g = img.astype(np.float64)
         ok = (np.abs(g - ref) <= 1e-3 + 1e-2 * np.abs(ref)).all(-1)
         assert ok[fin].mean() >= 0.97, (seed, ok[fin].mean())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_REGEN_SEEDS", "6"))))
+def test_random_scene_regenerating_form_equals_queue_form(pt, gpu_ctx, seed):
+    """The regenerating level-0 kernel on random scenes (all four materials or diffuse only, several lights, random camera,
+    integrator and roulette limits, both arithmetic modes) at sizes above the hand-off threshold: the film, the counters and
+    the deepest vertex equal those of the queue form -- which the test above pins to the f32 oracle on the same kind of
+    scene -- NaNs included.  Which lane traces which path there depends on the timing of the chunk counters."""
+    import torch
+    rng = np.random.default_rng(77000 + seed)
+    objs = random_scene(pt, rng, int(rng.integers(3, 40)))
+    if seed % 2 == 1:                     # Lambertian / emissive only: the DIFFUSE variant (the product default for such scenes)
+        for o in objs:
+            if o.mat_tag not in (0, 1):
+                o.mat_tag = 0
+                o.mat[0], o.mat[1], o.mat[2] = 0.6, 0.5, 0.4
+    w, h = int(rng.integers(500, 800)), int(rng.integers(400, 700))
+    spp = -(-(1 << 22) // (w * h)) + int(rng.integers(1, 6))              # more than 2^22 paths in the batch
+    cam = pt.camera_look_at(tuple(rng.uniform([-0.8, -0.8, 0.5], [0.8, 0.8, 2.5])), (0.0, 0.0, -2.0), (0.0, 1.0, 0.0),
+                            w, h, float(rng.uniform(25, 60)))
+    prm = pt.default_params(spp=spp, integrator=int(rng.integers(0, 2)), min_depth=int(rng.integers(0, 6)),
+                            max_depth=int(rng.integers(6, 30)), exact_math=int(seed % 3 == 0), accel=0)
+    gpu_ctx.upload(objs)
+    try:
+        gpu_ctx.set_tuning(level0_form=1)
+        ref, ref8 = gpu_ctx.render(cam, prm)
+        base = gpu_ctx.stats()
+        eb = int(rng.choice([0, 0, 5, 64]))
+        gpu_ctx.set_tuning(level0_form=2, regen_workgroups=int(rng.choice([0, 0, 97, 3000])), export_below=eb)
+        lin, rgba = gpu_ctx.render(cam, prm)
+        st = gpu_ctx.stats()
+        # the forms really were the two: level-0 + continuation launch; one regenerating launch whose waves run dry
+        # (with a hand-over threshold: + the continuation launch)
+        assert base.bounce_launches == 2 and st.bounce_launches == (1 if eb == 0 else 2)
+    finally:
+        gpu_ctx.set_tuning()
+    a, b = lin.cpu().numpy(), ref.cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True), f"seed {seed}: {(a != b).any(-1).sum()} pixels differ"
+    assert torch.equal(rgba, ref8)
+    assert (st.vertices, st.shadow_rays, st.max_depth_reached) == (base.vertices, base.shadow_rays, base.max_depth_reached)
