@@ -20,7 +20,7 @@
 // RNG.  The reference draws from rand 0.9.2 StdRng (ChaCha12), one sequential
 // stream per pixel seeded (y<<32)|x (src/main.rs:51-52).  That crate is not in
 // the tree.  This build keeps the seeding convention and the draw ORDER but
-// addresses every draw as philox(key=(x,y), ctr=(sample, depth, block, 0)) so
+// addresses every draw as philox(ctr=(x, y, sample, depth), key=(block, 0)) so
 // that a wavefront may evaluate vertices in any order.
 //
 // Two instantiations:
@@ -90,11 +90,12 @@ inline double u01(uint32_t r) { return (double)(((r >> 9) << 1) | 1u) * (1.0 / 1
 inline uint32_t rr_word(const uint32_t ds[4]) { return (ds[0] << 23) | ((ds[1] & 0x1FFu) << 14) | ((ds[2] & 0x1FFu) << 5); }
 
 struct Draws {
-    uint32_t key[2];   // (x, y): low/high word of the reference seed (y<<32)|x, main.rs:51
+    uint32_t key[2];   // (x, y): low/high word of the reference seed (y<<32)|x, main.rs:51 -- the first two counter words
     uint32_t sample;
     void block(uint32_t depth, uint32_t blk, uint32_t out[4]) const {
-        uint32_t c[4] = {sample, depth, blk, 0u};
-        philox4x32_10(c, key, out);
+        uint32_t c[4] = {key[0], key[1], sample, depth};     // counter = (x, y, sample, depth)
+        uint32_t k[2] = {blk, 0u};                           // key = (block, 0)
+        philox4x32_10(c, k, out);
     }
 };
 

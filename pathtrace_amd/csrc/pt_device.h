@@ -112,8 +112,9 @@ PT_DEV void sincos2pi(float u, float& s, float& c) {
 }
 
 // ------------------------------------------------------------------ counter RNG
-// Philox4x32-10 (Random123).  key = (x, y) = the two words of the reference's
-// per-pixel seed (y<<32)|x (src/main.rs:51); ctr = (sample, depth, block, 0).
+// Philox4x32-10 (Random123).  ctr = (x, y, sample, depth) -- (x, y) = the two words of the reference's per-pixel seed
+// (y<<32)|x (src/main.rs:51) --, key = (block, 0): the key is a literal at every call, so the ten round keys are
+// constants and the key schedule costs no instruction (with the pixel in the key it was 20 VALU adds per call).
 PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                           uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -128,7 +129,7 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// Draw blocks of a vertex, ctr = (sample, depth, block, 0):
+// Draw blocks of a vertex, ctr = (x, y, sample, depth), key = (block, 0):
 //   BLK_SURFACE: [0] light r1 [1] light r2 [2] bsdf r1 [3] bsdf r2     (shape.rs:111-112,211-212; material.rs:100-101,
 //                                                                      mirror.rs:42-43)
 //   BLK_CHOICE:  [0] light index (world.rs:255) [1] Mirror lobe u (mirror.rs:232) [2] Russian roulette u

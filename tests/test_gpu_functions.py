@@ -138,7 +138,7 @@ def test_camera_ray_device_function(pt, orc, gpu_ctx):
     for cam in (pt.camera_new(width=400, height=400), pt.camera_look_at((0.6, 0.3, 1.8), (0.0, -0.3, -2.0), (0, 1, 0), 96, 40, 40.0)):
         n = 2000
         xys = np.stack([rng.integers(0, cam.width, n), rng.integers(0, cam.height, n), rng.integers(0, 5000, n)], 1).astype(np.uint32)
-        off = np.array([[orc.u01(w) for w in orc.philox((int(s), 0xFFFFFFFF, 0, 0), (int(x), int(y)))[:2]] for x, y, s in xys])
+        off = np.array([[orc.u01(w) for w in orc.philox((int(x), int(y), int(s), 0xFFFFFFFF), (0, 0))[:2]] for x, y, s in xys])
         # world.rs:299 hands get_ray_with_offset the flipped row HEIGHT-1-y
         flipped = np.stack([xys[:, 0], cam.height - 1 - xys[:, 1]], 1)
         ref = orc.camera_rays(cam, flipped, off, F64)

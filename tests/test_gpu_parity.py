@@ -233,7 +233,7 @@ def test_full_size_exact_mode_is_bit_identical_to_the_f32_oracle(pt, orc, gpu_ct
 _REF_CACHE = {}
 
 
-def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.01, **kw):
+def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.01, chaotic=False, **kw):
     """SURVEY 8(d) parity bar (iii): GPU f32 (DEFAULT arithmetic, what bench.py measures) against the f64
     reference-faithful recursive oracle at `spp` samples per pixel.
     (1) Same sample indices: the two films differ only by f32 rounding and rare branch flips -- far below the
@@ -257,7 +257,13 @@ def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.
     lit = sigma > 0
     # (1) same samples: rounding-level agreement
     d_same = same - ref
-    assert abs(d_same.mean()) <= 1e-3 * ref.mean(), (d_same.mean(), ref.mean())
+    # image-mean relative error <= 1e-3.  In a chaotic scene f32 and f64 paths of the same sample decorrelate
+    # after a few bounces, and the "same-sample" difference is then itself Monte-Carlo noise: there the bound is what (2)
+    # applies to independent films, 3 sigma of the image-mean difference, where that is the larger one.
+    mean_tol = 1e-3 * ref.mean()
+    if chaotic:
+        mean_tol = max(mean_tol, 3.0 * np.sqrt(2.0 * (sigma[lit] ** 2).sum()) / lit.sum())
+    assert abs(d_same.mean()) <= mean_tol, (d_same.mean(), ref.mean(), mean_tol)
     assert np.mean(np.abs(d_same[lit]) <= 0.5 * sigma[lit]) >= same_frac, np.mean(np.abs(d_same[lit]) <= 0.5 * sigma[lit])
     # (2) independent samples: differences are noise, not bias
     z = (other - ref)[lit] / (np.sqrt(2.0) * sigma[lit])
@@ -299,5 +305,5 @@ def test_ten_thousand_spheres_show_no_bias_at_1024_spp(pt, orc, gpu_ctx, accel):
     objs = pt.builtin_scene(4, 10000)
     cam = pt.camera_new(width=32, height=32)
     # same-sample agreement is per-pixel only as far as paths stay correlated: demand it of 90 % of the pixels
-    lit, spread = _no_bias(pt, orc, gpu_ctx, objs, cam, 1024, parts=16, same_frac=0.90, outliers=0.08, accel=accel)
+    lit, spread = _no_bias(pt, orc, gpu_ctx, objs, cam, 1024, parts=16, same_frac=0.90, outliers=0.08, chaotic=True, accel=accel)
     assert lit > 0.5

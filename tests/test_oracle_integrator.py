@@ -150,7 +150,7 @@ def test_spp_offset_partitions_the_sample_set(pt, orc):
     assert np.allclose((a + b) / 2, full, rtol=1e-13)
 
 
-def test_row_bands_partition_the_image(pt, orc):                  # pixels are independent: key = (x, y), main.rs:51
+def test_row_bands_partition_the_image(pt, orc):                  # pixels are independent: the stream is addressed by (x, y), main.rs:51
     objs = pt.builtin_scene(1)
     cam = pt.camera_new(width=20, height=22)
     full, full8, _ = orc.render(cam, objs, pt.default_params(spp=2), F32, ITER)
