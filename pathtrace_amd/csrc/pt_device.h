@@ -142,7 +142,8 @@ constexpr uint32_t kDepthCamera = 0xFFFFFFFFu;
 // 23-bit uniform on the open interval (0,1): (2k+1)/2^24, exact in f32.
 // Evaluated without an integer-to-float conversion: bits(1 + k/2^23) minus (1 - 2^-24); the sum is representable,
 // so the one rounding of the add is exact and the value is (2k+1)/2^24 bit for bit.
-PT_DEV float u01(uint32_t r) { return __uint_as_float((r >> 9) | 0x3F800000u) + (-0.99999994f); }
+// (r >> 9) | 0x3F800000 in ONE instruction: v_alignbit_b32 takes bits [40:9] of {0x7F, r}.
+PT_DEV float u01(uint32_t r) { return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, r, 9u)) + (-0.99999994f); }
 
 // ------------------------------------------------------------------ scene records
 // shape record, 3 float4 per object:
