@@ -4,7 +4,7 @@
 use pathtrace_amd_sys as sys;
 use std::ffi::CStr;
 
-pub use sys::{PtCamera as Camera, PtObject as Object, PtRenderParams as RenderParams, PtStats as Stats};
+pub use sys::{PtCamera as Camera, PtObject as Object, PtRenderParams as RenderParams, PtStats as Stats, PtTuning as Tuning};
 
 #[derive(Debug)]
 pub struct Error {
@@ -115,6 +115,11 @@ impl Renderer {
         let mut s = Stats::default();
         check(unsafe { sys::pt_get_stats(self.ctx, &mut s) })?;
         Ok(s)
+    }
+    /// Scheduling knobs (`pt_context_set_tuning`; `Tuning::default()` = the library's choices).  The film and the
+    /// counters never depend on them: they exist for measurements (which kernel form a launch takes, grid sizes).
+    pub fn set_tuning(&mut self, tuning: &Tuning) -> Result<(), Error> {
+        check(unsafe { sys::pt_context_set_tuning(self.ctx, tuning) })
     }
     /// `World::render_pixel` (`world.rs:293-333`) for a pixel list: every listed pixel gets exactly the samples a
     /// full render gives it.  `want_samples`: also the radiance of every camera sample, `[pixel][sample][rgb]`
