@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both launch forms work for every N (launch_mode() below): under torch.distributed.run it is one process per GPU
+(pathtrace_amd/dist.py: pack kernel, ONE dist.gather over RCCL, unpack kernel); started as a plain process with
+--gpus N > 1 it is the library's single-process form (pt_multi_*: one context per device, ONE ncclGather inside
+an ncclGroup, include/pathtrace_amd.h) -- no launcher needed and no re-exec after the GPU has been touched.
+
 A step = one complete render of the workload through the C ABI (pt_render_device):
 camera-ray generation, every bounce launch, film resolve, and for N > 1 the single
 RCCL gather of the framebuffer to rank 0.  Scene and camera are resident in HBM
@@ -56,51 +61,85 @@ F_SPHERE, F_TRIANGLE, F_SHADE = 23, 51, 200     # flops per primiti
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
-def cpu_baseline(pt, objs):
-    """Oracle (kind "port") on the host: C2 at the bench camera, a row subset spread over the image.
-    Threads = the box's CPU share for one GPU (16), never more than the affinity mask allows.  A short
-    probe sizes the sample so that the timed run is ~10 s of wall time (bounded)."""
+def launch_mode(gpus, env, force_dist=False, force_multi=False):
+    """How this process takes part in an N-GPU run -> (mode, world, rank, local_rank).
+      "dist"    one process per GPU under torch.distributed.run (WORLD_SIZE > 1 in the environment, or --force-dist):
+                the environment's world size wins over --gpus;
+      "multi"   ONE plain process and --gpus N > 1 (or --force-multi): the library's pt_multi_* path over N devices;
+      "single"  one GPU, no collective."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    if force_dist and force_multi:
+        raise SystemExit("--force-dist and --force-multi exclude each other")
+    if world > 1 or force_dist:
+        if force_multi:
+            raise SystemExit("--force-multi is the single-process form: do not start it under torch.distributed.run")
+        return "dist", world, rank, local_rank
+    if gpus > 1 or force_multi:
+        return "multi", max(1, gpus), 0, 0
+    return "single", 1, 0, 0
+
+
+def cpu_baseline(pt, objs, width, height, spp_full, desc):
+    """Oracle (kind "port") on the host: the workload's scene at the bench camera, a row subset spread over the image.
+    Threads = the box's CPU share for one GPU (16), never more than the affinity mask allows; `all_cores` repeats a bounded
+    run on every CPU the process may use (north_star: "host cores (core count stated)"; the reference's rayon loop,
+    main.rs:48, takes all of them).  A short probe sizes the samples so that each timed run is ~10 s of wall time."""
     from oracle import orc
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))
-    cam = pt.camera_new(width=WIDTH, height=HEIGHT)
+    cam = pt.camera_new(width=width, height=height)
 
-    def run(spp, band_count):
+    def run(spp, band_count, threads):
         prm = pt.default_params(spp=spp, band_rows=1, band_index=0, band_count=band_count)
         t0 = time.perf_counter()
-        lin, _, _ = orc.render(cam, objs, prm, orc.F64, orc.RECURSIVE, threads=cores)
+        lin, _, _ = orc.render(cam, objs, prm, orc.F64, orc.RECURSIVE, threads=threads)
         return lin.shape[0], time.perf_counter() - t0
 
-    rows, dt = run(1, 16)                                   # probe: 64 rows x 1 spp
-    rate = rows * WIDTH / dt                                # samples / s
-    # timed run: full 64 spp on every band_count-th row, band_count chosen for ~10 s of wall time
-    band_count = 16
-    for bc in (8, 4, 2, 1):
-        if (HEIGHT // bc) * WIDTH * SPP / rate <= 12.0:
-            band_count = bc
-    spp = SPP if (HEIGHT // band_count) * WIDTH * SPP / rate <= 30.0 else int(max(1, 30.0 * rate / (64 * WIDTH)))
-    rows, dt = run(spp, band_count)
-    samples = rows * WIDTH * spp
+    def timed(threads, budget_s):
+        rows, dt = run(1, 64, threads)                      # probe: every 64th row x 1 spp
+        rate = rows * width / dt                            # samples / s
+        # full spp on every band_count-th row; fewer samples per pixel only if even every 64th row is too much
+        band_count, spp = 64, spp_full
+        for bc in (32, 16, 8, 4, 2, 1):
+            if len(range(0, height, bc)) * width * spp_full / rate <= budget_s:
+                band_count = bc
+        rows = len(range(0, height, band_count))
+        if rows * width * spp_full / rate > 2.5 * budget_s:
+            spp = int(max(1, 2.5 * budget_s * rate / (rows * width)))
+        rows, dt = run(spp, band_count, threads)
+        return rows, spp, band_count, dt
+
+    rows, spp, band_count, dt = timed(cores, 12.0)
+    samples = rows * width * spp
+    out = {
+        "value": round(samples / dt / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{desc}, {width}x{height} camera, every {band_count}th row ({rows} rows), {spp} of {spp_full} spp = "
+                  f"{samples} samples in {dt:.2f} s wall; oracle f64 recursive (reference-shaped: linear scan, "
+                  f"3 scans per vertex), {cores} threads over pixels ({avail} CPUs visible)",
+    }
+    if avail > cores:
+        rows, spp, band_count, dt = timed(avail, 8.0)
+        out["all_cores"] = {"value": round(rows * width * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": avail,
+                            "sample": f"same oracle on every visible CPU: every {band_count}th row ({rows} rows), {spp} spp in {dt:.2f} s wall"}
+    else:
+        out["all_cores"] = {"value": out["value"], "unit": "Msamples/s", "cores": avail, "sample": "the figure above already uses every visible CPU"}
     # BASELINE.json configs[0]: the reference's own scene, 256 x 256, 4 spp, ONE thread (the scalar port)
     c1_objs = pt.builtin_scene(1)
     c1_cam = pt.camera_new(width=256, height=256)
     t0 = time.perf_counter()
     orc.render(c1_cam, c1_objs, pt.default_params(spp=4), orc.F64, orc.RECURSIVE, threads=1)
     c1_dt = time.perf_counter() - t0
-    return {
-        "value": round(samples / dt / 1e6, 4),
-        "unit": "Msamples/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"C2 scene, {WIDTH}x{HEIGHT} camera, every {band_count}th row ({rows} rows), {spp} of {SPP} spp = "
-                  f"{samples} samples in {dt:.2f} s wall; oracle f64 recursive (reference-shaped: linear scan, "
-                  f"3 scans per vertex), {cores} threads over pixels ({avail} CPUs visible)",
-        "config0_single_thread": {"value": round(256 * 256 * 4 / c1_dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
-                                  "sample": f"C1 reference scene, 256x256, 4 spp = 262144 samples in {c1_dt:.2f} s"},
-    }
+    out["config0_single_thread"] = {"value": round(256 * 256 * 4 / c1_dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                                    "sample": f"C1 reference scene, 256x256, 4 spp = 262144 samples in {c1_dt:.2f} s"}
+    return out
 
 
 def profile_summary(world, workload, accel):
@@ -123,7 +162,7 @@ def profile_summary(world, workload, accel):
         return None
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -145,26 +184,27 @@ def main():
                          "goes through host memory); the driver's runs use nccl (RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with one rank: still initialise the process group and run every collective of the N > 1 path "
-                         "(rehearsal of that code over real RCCL on a one-GPU box)")
-    args = ap.parse_args()
+                         "(rehearsal of the one-process-per-GPU code over real RCCL on a one-GPU box)")
+    ap.add_argument("--force-multi", action="store_true",
+                    help="with --gpus 1: still run the single-process multi-device path (pt_multi_*: ncclCommInitAll, the "
+                         "ncclGather, the row permutation) -- its rehearsal over real RCCL on a one-GPU box")
+    args = ap.parse_args(argv)
+
+    mode, world, rank, local_rank = launch_mode(args.gpus, os.environ, args.force_dist, args.force_multi)
 
     import torch
     import torch.distributed as dist
     import pathtrace_amd as pt
     from pathtrace_amd.dist import FilmGather, default_band_rows
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
-        args.gpus = world
-    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    args.gpus = world
+    if mode == "multi" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world}: this host shows {torch.cuda.device_count()} GPU(s)")
+    dev_index = local_rank if (mode != "dist" or args.backend == "nccl") else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    multi = world > 1 or args.force_dist        # run the distributed code path
-    if multi:
+    dist_path = mode == "dist"                  # one process per GPU: process group + dist.gather
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
@@ -175,35 +215,42 @@ def main():
 
     global WIDTH, HEIGHT, SPP
     scene_id, scene_arg, WIDTH, HEIGHT, SPP, wl_desc = WORKLOADS[args.workload]
-    if args.workload != "c2":
-        args.no_cpu_baseline = True          # the CPU baseline leg is defined on the headline config
     objs = pt.builtin_scene(scene_id, scene_arg)
     cam = pt.camera_new(width=WIDTH, height=HEIGHT)
     spp = SPP * world if args.weak else SPP
-    band_rows = default_band_rows(HEIGHT, world) if multi else 0
-    prm = pt.default_params(spp=spp, band_rows=band_rows, band_index=rank, band_count=world, profile=1,
-                            max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
-    ctx = pt.Context(dev_index)
-    ctx.upload(objs)
-    ctx.set_tuning(cont_workgroups=args.cont_workgroups, export_below=args.export_below, level0_form=args.level0_form,
-                   regen_workgroups=args.regen_workgroups)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    rows = pt.tile_rows(HEIGHT, band_rows, rank, world)
+    band_rows = default_band_rows(HEIGHT, world) if mode != "single" else 0
+    tuning = dict(cont_workgroups=args.cont_workgroups, export_below=args.export_below, level0_form=args.level0_form,
+                  regen_workgroups=args.regen_workgroups)
+    common = dict(spp=spp, profile=1, max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
+    if mode == "multi":
+        # ONE process, `world` devices: every device renders its interleaved bands, ONE ncclGather to device 0 (pt_multi.cpp)
+        prm = pt.default_params(band_rows=band_rows, **common)
+        ctx = pt.Multi(list(range(world)))
+        ctx.upload(objs)
+        ctx.set_tuning(**tuning)
+        rows = HEIGHT                           # the frame is assembled on device 0 by the library
+    else:
+        prm = pt.default_params(band_rows=band_rows, band_index=rank, band_count=world, **common)
+        ctx = pt.Context(dev_index)
+        ctx.upload(objs)
+        ctx.set_tuning(**tuning)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        rows = pt.tile_rows(HEIGHT, band_rows, rank, world)
     lin = torch.empty((rows, WIDTH, 3), dtype=torch.float32, device=dev)
     rgba = torch.empty((rows, WIDTH, 4), dtype=torch.uint8, device=dev)
 
     acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0,
            "p_vertices": 0, "p_ms": 0.0, "p_launches": 0, "shadow_rays": 0}
 
-    # the single exchange step of the path: one gather of the framebuffer (f32 + RGBA8 packed) per step.  It is
-    # launched asynchronously, so the gather of step k runs (on the backend's stream) while step k + 1 renders; the
-    # last one is completed inside the timed region.
-    film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev, always_collective=True) if multi else None
+    # one process per GPU: the single exchange step of the path is one gather of the framebuffer (f32 + RGBA8 packed) per
+    # step.  It is launched asynchronously, so the gather of step k runs (on the backend's stream) while step k + 1 renders;
+    # the last one is completed inside the timed region.  (Single-process form: the gather is inside render_into.)
+    film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev, always_collective=True) if dist_path else None
 
     def step(record):
         ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         ctx.sync()
-        if multi:
+        if dist_path:
             film_gather.start(lin.to(comm_dev), rgba.to(comm_dev))
         if record:
             st = ctx.stats()
@@ -218,25 +265,29 @@ def main():
             acc["p_launches"] += st.primary_launches
 
     def barrier():
-        if multi:
+        if dist_path:
             dist.barrier()
+
+    def device_sync():
+        for d in (range(world) if mode == "multi" else [dev_index]):
+            torch.cuda.synchronize(d)
 
     frame = frame8 = None
     for _ in range(args.warmup):
         step(False)
-    if multi:
+    if dist_path:
         film_gather.finish()
     barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if multi:
+    if dist_path:
         frame, frame8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
-    torch.cuda.synchronize()
+    device_sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    if multi:
+    if dist_path:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -244,27 +295,38 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_samples = float(tot[1].item())
     else:
-        job_samples = float(acc["samples"])
+        job_samples = float(acc["samples"])     # pt_multi_get_stats sums over the devices
 
     if rank == 0:
-        if multi:
+        if dist_path:
             assert frame is not None and tuple(frame.shape) == (HEIGHT, WIDTH, 3) and torch.isfinite(frame).all()
             if world == 1:
                 assert torch.equal(frame, lin) and torch.equal(frame8, rgba)     # --force-dist: the gathered frame is the tile
         else:
             assert torch.isfinite(lin).all()
+        if mode == "multi" and world == 1:
+            # --force-multi: the frame that went through ncclGather + row permutation is the plain render, bit for bit
+            ref_ctx = pt.Context(0)
+            ref_ctx.upload(objs)
+            ref_lin, ref_rgba = ref_ctx.render(cam, pt.default_params(**common))
+            assert torch.equal(ref_lin, lin) and torch.equal(ref_rgba, rgba)
+            ref_ctx.close()
         # the dominant kernel = the level-0 launch of each batch (camera rays + every bounce until its waves hand
-        # their sparse tails over); it processes p_vertices of the vertices and all of the camera samples
+        # their sparse tails over); it processes p_vertices of the vertices and all of the camera samples.
+        # Single-process multi-device runs: counters are sums over the devices, launch times the slowest device's
+        # (pt_multi_get_stats), so the per-device figures below divide the work by the device count.
+        n_stat = world if mode == "multi" else 1
         n_sph = sum(1 for o in objs if o.shape_tag == 0)
         n_tri = len(objs) - n_sph
         f_scan = F_SPHERE * n_sph + F_TRIANGLE * n_tri                       # one linear scan of the scene
         share = acc["p_vertices"] / max(acc["vertices"], 1)                  # the level-0 launches' share of the work
         scans = acc["p_vertices"] + acc["shadow_rays"] * share               # closest-hit scans + visibility scans
-        alg_flops = f_scan * scans + F_SHADE * acc["p_vertices"]
+        alg_flops = (f_scan * scans + F_SHADE * acc["p_vertices"]) / n_stat
+        p_launches = acc["p_launches"] / n_stat
         achieved_tf = alg_flops / (acc["p_ms"] * 1e-3) / 1e12 if acc["p_ms"] > 0 else 0.0
-        alg_bytes = BYTES_PER_VERTEX * acc["p_vertices"] + BYTES_PER_SAMPLE * acc["samples"]
-        avg_ms = acc["p_ms"] / max(acc["p_launches"], 1)
-        prof = profile_summary(world, args.workload, args.accel)
+        alg_bytes = (BYTES_PER_VERTEX * acc["p_vertices"] + BYTES_PER_SAMPLE * acc["samples"]) / n_stat
+        avg_ms = acc["p_ms"] / max(p_launches, 1)
+        prof = profile_summary(world if mode != "multi" else 0, args.workload, args.accel)
         accel_name = {0: "linear scan (reference)", 1: "BVH traversal (accel=1, same film as the linear scan)",
                       2: "PT_ACCEL_AUTO (product default: BVH above ~512 sphere tests per scan, same film)"}[args.accel]
         diffuse = all(o.mat_tag in (0, 1) for o in objs)
@@ -273,7 +335,7 @@ def main():
         elif len(objs) <= 128:
             # large batches over a scene in LDS: the regenerating form where the library takes it (pt_api.cpp: diffuse scenes
             # by default, PtTuning.level0_form), the queue form otherwise
-            big = acc["samples"] / max(acc["p_launches"], 1) > (1 << 22)
+            big = acc["samples"] / n_stat / max(p_launches, 1) > (1 << 22)
             if big and (args.level0_form == 2 or (args.level0_form == 0 and diffuse)):
                 kernel = "k_paths_regen<MIS, %s>" % ("DIFFUSE" if diffuse else "generic")
             else:
@@ -285,22 +347,23 @@ def main():
                                 "whose path ends takes the batch's next one)" if kernel.startswith("k_paths_regen") else
                                 ": the level-0 launch of a sample batch (camera rays + every bounce until the waves hand "
                                 "over their sparse tails)") +
-                      ", rank 0.  Bound by f32 VALU issue (no contraction on this path: the "
+                      (", rank 0" if mode != "multi" else ", per device (work / devices over the slowest device's launch time)") +
+                      ".  Bound by f32 VALU issue (no contraction on this path: the "
                       "schema's mfma slot does not apply; same 157.3 TFLOP/s f32 peak)",
             "bound": "valu",
             "achieved": round(achieved_tf, 2),
             "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved_tf / VALU_PEAK_TFLOPS, 4),
-            "algorithmic_flops_per_launch": round(alg_flops / max(acc["p_launches"], 1)),
+            "algorithmic_flops_per_launch": round(alg_flops / max(p_launches, 1)),
             "flops_model": f"{f_scan} per scan of the scene ({n_sph} spheres x {F_SPHERE} + {n_tri} triangles x {F_TRIANGLE}) x "
                            f"(vertices + visibility scans) + {F_SHADE} per vertex (SURVEY 8d)",
             "avg_launch_ms": round(avg_ms, 4),
-            "launches": acc["p_launches"],
+            "launches": int(p_launches),
             "vertex_share": round(share, 4),
             "all_path_kernels_ms_per_step": round(acc["bounce_ms"] / max(args.steps, 1), 4),
             "traffic": None, "hbm_frac": None, "valu_issue_frac": None,
-            "algorithmic_bytes_per_launch_unfused_pipeline": round(alg_bytes / max(acc["p_launches"], 1)),
+            "algorithmic_bytes_per_launch_unfused_pipeline": round(alg_bytes / max(p_launches, 1)),
         }
         bvh_run = args.accel == 1 or (args.accel == 2 and len(objs) > 512)
         if bvh_run:
@@ -325,6 +388,15 @@ def main():
                 roof["valu_insts_per_launch"] = int(prof["valu_insts_per_launch"])
             roof["counters_source"] = f"{src}: replayed from the committed rocprofv3 passes of this command ({prof.get('kernel')}, " \
                                       f"{prof.get('avg_launch_ms_kernel_trace', 0):.3f} ms per launch in the profiled process), not measured in this run"
+        if world == 1:
+            tiles = "whole image" + (" (through the single-process multi-device path: ncclCommInitAll over 1 device, ONE ncclGather, row "
+                                     "permutation; frame checked bitwise against the plain render)" if mode == "multi" else "")
+        elif mode == "multi":
+            tiles = (f"interleaved bands of {band_rows} rows over {world} devices driven by ONE process (pt_multi_*): ONE ncclGather "
+                     f"(RCCL, inside one ncclGroup) of the packed f32 + RGBA8 tiles to device 0 per step, then the row permutation there")
+        else:
+            tiles = (f"interleaved bands of {band_rows} rows over {world} ranks, ONE {args.backend} gather of the packed f32 + RGBA8 "
+                     f"frame to rank 0 per step, overlapped with the next step's rendering")
         out = {
             "metric": ("Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2"
                        else f"Msamples/sec (pixels x spp / s) at {WIDTH}x{HEIGHT}/{SPP}spp") +
@@ -336,7 +408,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak" if (args.weak or world == 1) else "strong",
+            "scaling": "weak" if args.weak else "strong",       # the job (1024^2 x 64 spp) is fixed as N grows unless --weak
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -345,16 +417,17 @@ def main():
                 "hit_scene": accel_name,
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
-                "tiles": "whole image" if world == 1 else f"interleaved bands of {band_rows} rows over {world} ranks, "
-                                                          f"ONE {args.backend} gather of the packed f32 + RGBA8 frame to rank 0 per step, overlapped with the next step's rendering",
+                "launch": {"single": "one process, one GPU", "multi": "one process, all GPUs (pt_multi_*)",
+                           "dist": "one process per GPU (torch.distributed)"}[mode],
+                "tiles": tiles,
             },
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pt, objs)
+            out["cpu_baseline"] = cpu_baseline(pt, objs, WIDTH, HEIGHT, SPP, wl_desc.split(":")[0] + " scene")
         print(json.dumps(out), flush=True)
     ctx.close()
-    if multi:
+    if dist_path:
         dist.destroy_process_group()
 
 

@@ -92,8 +92,12 @@ typedef struct {
     uint32_t band_rows;
     uint32_t band_index;
     uint32_t band_count;
-    /* Wavefront sizing: upper bound on paths resident in HBM at once
-     * (0 = library default).                                                  */
+    /* Wavefront sizing: upper bound on paths resident in HBM at once (0 = library default).  It sizes the
+     * context's device buffers, which persist between renders: the default is 2^26 paths (76 B of queue + 12 B of
+     * sample buffer each, only as many as the job has) and 2^28 where the level-0 launch keeps its paths in
+     * registers (diffuse scenes of <= 128 objects: 12 B of sample buffer per path, i.e. up to 3.2 GB per context
+     * for a render of >= 2^28 samples -- the 400 x 400 x 3000 default job included).  A host that shares the GPU
+     * sets a smaller bound: the job is then cut into more sample batches, with the same film.                */
     uint64_t max_paths_in_flight;
     uint32_t profile;        /* 1: time every path-kernel launch with HIP events */
     /* Workgroups (256 threads) of the path kernel; every wave owns one private queue
@@ -247,6 +251,7 @@ int pt_multi_create(const int* devices, uint32_t n_devices, PtMulti** out);   /*
 int pt_multi_destroy(PtMulti* m);
 uint32_t pt_multi_device_count(const PtMulti* m);
 int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs);  /* replicated on every device */
+int pt_multi_set_tuning(PtMulti* m, const PtTuning* tuning);                   /* pt_context_set_tuning on every device's context */
 /* Enqueue one frame: d_linear_rgb (H*W*3 floats) / d_rgba8 (H*W*4 bytes or NULL) are buffers on the FIRST device.
  * params->band_rows = 0 picks about eight bands per device; band_index / band_count are ignored.            */
 int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams* params,
@@ -262,6 +267,8 @@ int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam,
 /* The two kernels pt_multi_* runs around its ncclGather, for hosts that bring their own collective (one process per GPU:
  * pathtrace_amd/dist.py over torch.distributed / RCCL, an MPI host, ...).  Both work on DEVICE memory of the calling
  * thread's current HIP device and are enqueued on hip_stream (a hipStream_t; NULL = that device's default stream).
+ * The caller guarantees that hip_stream was created on that current device (hipSetDevice before the call in a
+ * multi-device host): a stream of another device makes the launch fail with PT_ERR_HIP, it is not redirected.
  *   pt_film_pack:   a rank's tile (d_linear_rgb: n_pixels * 3 floats, d_rgba8: n_pixels * 4 bytes or NULL) ->
  *                   d_packed, 16 bytes per pixel (12 B linear RGB + 4 B RGBA8): both film planes in ONE gather.
  *   pt_film_unpack: the gathered tiles (rank g's tile, padded to max_rows rows, at d_gathered + g * max_rows * width *

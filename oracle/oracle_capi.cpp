@@ -335,3 +335,33 @@ extern "C" int orc_trace_path(const PtCamera* pc, const PtObject* objs, uint32_t
     std::memcpy(rec, tr.rec.data(), (size_t)m * 24 * sizeof(double));
     return nv;
 }
+
+// World::render_pixel (world.rs:293-333) for a pixel list, with the radiance of every camera sample (what the
+// reference's pixel diagnostics print, world.rs:378-417): xy n*2 = (x, y top-down film row); out_lin n*3 (may be
+// null); out_samples n*spp*3 (may be null) in sample order.  The replay tool of the full-size parity tests.
+template <class R>
+static void render_pixels_impl(const PtCamera* pc, const PtObject* objs, uint32_t nobj, const PtRenderParams* pp, int form,
+                               const uint32_t* xy, uint32_t n, double* out_lin, double* out_samples) {
+    Scene<R> scene = build_scene<R>(objs, nobj);
+    Camera<R> cam = make_camera<R>(pc);
+    Params prm = make_params(pp);
+    Counters cn;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t x = xy[2 * i], y = xy[2 * i + 1];
+        double acc[3] = {0, 0, 0};
+        for (uint32_t s = 0; s < pp->spp; ++s) {
+            double lin[3]; uint8_t rg[4];
+            render_pixel<R>(scene, cam, prm, (Form)form, x, y, 1, pp->spp_offset + s, lin, rg, cn);   // one sample: mean = the sample
+            if (out_samples) std::memcpy(out_samples + ((size_t)i * pp->spp + s) * 3, lin, sizeof lin);
+            for (int k = 0; k < 3; ++k) acc[k] += lin[k];
+        }
+        if (out_lin) for (int k = 0; k < 3; ++k) out_lin[3 * (size_t)i + k] = acc[k] / (double)pp->spp;
+    }
+}
+extern "C" int orc_render_pixels(const PtCamera* cam, const PtObject* objs, uint32_t nobj, const PtRenderParams* p, int precision,
+                                 int form, const uint32_t* xy, uint32_t n, double* out_lin, double* out_samples) {
+    if (!cam || !objs || !p || p->spp == 0 || (n && !xy)) return 1;
+    if (precision == 64) render_pixels_impl<double>(cam, objs, nobj, p, form, xy, n, out_lin, out_samples);
+    else render_pixels_impl<float>(cam, objs, nobj, p, form, xy, n, out_lin, out_samples);
+    return 0;
+}

@@ -66,6 +66,19 @@ def render(cam, objs, params, precision=F64, form=RECURSIVE, threads=1):
                        "max_depth": int(cnt[3])}
 
 
+def render_pixels(cam, objs, params, xy, precision=F64, form=RECURSIVE):
+    """World::render_pixel for a pixel list -> (linear float64[n,3], samples float64[n,spp,3] in sample order)"""
+    xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+    n = xy.shape[0]
+    lin = np.zeros((n, 3), dtype=np.float64)
+    smp = np.zeros((n, params.spp, 3), dtype=np.float64)
+    rc = lib().orc_render_pixels(C.byref(cam), objs, C.c_uint32(len(objs)), C.byref(params), C.c_int(precision), C.c_int(form),
+                                 _p(xy), C.c_uint32(n), _p(lin), _p(smp))
+    if rc:
+        raise RuntimeError(f"orc_render_pixels failed: {rc}")
+    return lin, smp
+
+
 def hit_scene(objs, rays, t_min=0.001, t_max=float("inf"), precision=F64):
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     n = rays.shape[0]

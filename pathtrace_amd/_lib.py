@@ -127,6 +127,7 @@ SYMBOLS = {
     "pt_multi_destroy": (C.c_int, [C.c_void_p]),
     "pt_multi_device_count": (C.c_uint32, [C.c_void_p]),
     "pt_multi_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
+    "pt_multi_set_tuning": (C.c_int, [C.c_void_p, _P(PtTuning)]),
     "pt_multi_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_multi_sync": (C.c_int, [C.c_void_p]),
     "pt_multi_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),

@@ -293,6 +293,10 @@ class Multi:
         self._objs = objs
         check(lib().pt_multi_scene_upload(self._h, objs, len(objs)))
 
+    def set_tuning(self, export_below=0, bvh_refill=0, bvh_leaf=0, cont_workgroups=0, level0_form=0, regen_workgroups=0):
+        t = _lib.PtTuning(export_below, bvh_refill, bvh_leaf, cont_workgroups, level0_form, regen_workgroups)
+        check(lib().pt_multi_set_tuning(self._h, C.byref(t)))
+
     def render_into(self, cam, params, linear_ptr, rgba_ptr):
         check(lib().pt_multi_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(linear_ptr),
                                            C.c_void_p(rgba_ptr) if rgba_ptr else None))

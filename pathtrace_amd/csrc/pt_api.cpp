@@ -1018,9 +1018,14 @@ size_t tile_pixels(const PtCamera* cam, const PtRenderParams* prm) {
 // the contexts pt_render() keeps between calls (one per device it has been asked to use)
 std::mutex g_render_mu;
 std::vector<PtContext*> g_render_ctx;
-bool g_atexit_registered = false;
 
 }  // namespace
+
+// pt_shutdown at exit, registered once by whichever one-shot entry (pt_render, pt_render_multi) creates cached state first
+void pt_internal_register_atexit(void) {
+    static std::once_flag once;
+    std::call_once(once, [] { std::atexit(pt_shutdown); });
+}
 
 extern "C" {
 
@@ -1150,7 +1155,7 @@ int pt_render(const PtCamera* cam, const PtObject* objs, uint32_t n, const PtRen
         PtContext* ctx = nullptr;
         if ((rc = pt_context_create(0, &ctx))) return rc;
         g_render_ctx.push_back(ctx);
-        if (!g_atexit_registered) { std::atexit(pt_shutdown); g_atexit_registered = true; }
+        pt_internal_register_atexit();
     }
     PtContext* ctx = g_render_ctx[0];
     if ((rc = pt_scene_upload(ctx, objs, n))) return rc;

@@ -115,11 +115,14 @@ PT_DEV void sincos2pi(float u, float& s, float& c) {
 // Philox4x32-10 (Random123).  ctr = (x, y, sample, depth) -- (x, y) = the two words of the reference's per-pixel seed
 // (y<<32)|x (src/main.rs:51) --, key = (block, 0): the key is a literal at every call, so the ten round keys are
 // constants and the key schedule costs no instruction (with the pixel in the key it was 20 VALU adds per call).
+#ifndef PT_PHILOX_ROUNDS
+#define PT_PHILOX_ROUNDS 10
+#endif
 PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                           uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PT_PHILOX_ROUNDS; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0;
         uint64_t p1 = (uint64_t)M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -132,11 +135,14 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 // Draw blocks of a vertex, ctr = (x, y, sample, depth), key = (block, 0):
 //   BLK_SURFACE: [0] light r1 [1] light r2 [2] bsdf r1 [3] bsdf r2     (shape.rs:111-112,211-212; material.rs:100-101,
 //                                                                      mirror.rs:42-43)
-//   BLK_CHOICE:  [0] light index (world.rs:255) [1] Mirror lobe u (mirror.rs:232) [2] Russian roulette u
-//                (rendering.rs:100)
-// BLK_CHOICE is generated only where it can decide something: more than one light, a Mirror surface, or
-// depth >= MIN_DEPTH (below it rr = 1 and u < 1 always survives) -- one Philox call per vertex instead of two
-// on the first MIN_DEPTH bounces of a diffuse scene.
+//   BLK_CHOICE:  [0] light index (world.rs:255) [1] Mirror lobe u (mirror.rs:232) [2], [3] spare
+// The Russian-roulette uniform (rendering.rs:100) is made of the bits of BLK_SURFACE that u01() never looks at (the
+// low 9 bits of words 0 and 1, bits 8..4 of word 2: vertex_begin, oracle rr_word()).  BLK_CHOICE is generated only
+// where it can decide something -- more than one light, or a Mirror surface -- so a vertex of a diffuse one-light scene
+// costs ONE Philox call at every depth.
+// This addressing -- ctr (x, y, sample, depth), key (block, 0), the word assignment above, camera jitter at depth
+// 0xFFFFFFFF -- is part of the ABI since round 3: spp_offset resume, pt_render_pixels replays and any archived film
+// depend on it (DESIGN.md 1 "RNG").
 enum { BLK_SURFACE = 0, BLK_CHOICE = 1 };
 constexpr uint32_t kDepthCamera = 0xFFFFFFFFu;
 // 23-bit uniform on the open interval (0,1): (2k+1)/2^24, exact in f32.

@@ -25,6 +25,7 @@
 
 // defined in pt_api.cpp
 int pt_internal_fail(int code, const char* fmt, ...);
+void pt_internal_register_atexit(void);
 hipStream_t pt_internal_stream(PtContext* c);
 
 namespace {
@@ -103,7 +104,6 @@ struct PtMulti {
     std::vector<ncclComm_t> comm;
     std::vector<DevMem> lin, rgba, packed;     // per device: its tile (f32 RGB, RGBA8) and the 16 B/pixel send buffer
     DevMem recv, out_lin, out_rgba;            // root: gathered tiles; frame staging of the host entry
-    std::vector<hipEvent_t> done;              // per device: its part of the exchange is enqueued and complete
 };
 
 extern "C" {
@@ -118,7 +118,6 @@ int pt_multi_destroy(PtMulti* m) {
     for (auto& b : m->rgba) b.release();
     for (auto& b : m->packed) b.release();
     m->recv.release(); m->out_lin.release(); m->out_rgba.release();
-    for (size_t i = 0; i < m->done.size(); ++i) if (m->done[i]) { (void)hipSetDevice(m->devices[i]); (void)hipEventDestroy(m->done[i]); }
     for (PtContext* c : m->ctx) if (c) (void)pt_context_destroy(c);
     delete m;
     return PT_OK;
@@ -134,15 +133,11 @@ int pt_multi_create(const int* devices, uint32_t n, PtMulti** out) {
     if (rc) return rc;
     PtMulti* m = new PtMulti();
     m->devices.assign(devices, devices + n);
-    m->ctx.assign(n, nullptr); m->comm.assign(n, nullptr); m->done.assign(n, nullptr);
+    m->ctx.assign(n, nullptr); m->comm.assign(n, nullptr);
     m->lin.resize(n); m->rgba.resize(n); m->packed.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         if ((rc = pt_context_create(devices[i], &m->ctx[i]))) { pt_multi_destroy(m); return rc; }
         m->lin[i].device = m->rgba[i].device = m->packed[i].device = devices[i];
-        if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming) != hipSuccess) {
-            pt_multi_destroy(m);
-            return pt_internal_fail(PT_ERR_HIP, "pt_multi_create: event creation failed on device %d", devices[i]);
-        }
     }
     m->recv.device = m->out_lin.device = m->out_rgba.device = devices[0];
     const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), (int)n, devices);     // rccl.h:236
@@ -163,6 +158,12 @@ int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs) {
         const int rc = pt_scene_upload(c, objs, n_objs);     // the scene is replicated (<= 160 KB for the reference's scenes)
         if (rc) return rc;
     }
+    return PT_OK;
+}
+
+int pt_multi_set_tuning(PtMulti* m, const PtTuning* t) {
+    if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
+    for (PtContext* c : m->ctx) { const int rc = pt_context_set_tuning(c, t); if (rc) return rc; }
     return PT_OK;
 }
 
@@ -305,7 +306,10 @@ int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam,
         pt_multi_destroy(g_multi);
         g_multi = nullptr;
     }
-    if (!g_multi && (rc = pt_multi_create(devices, n_devices, &g_multi))) return rc;
+    if (!g_multi) {
+        if ((rc = pt_multi_create(devices, n_devices, &g_multi))) return rc;
+        pt_internal_register_atexit();       // a process that only ever renders on several devices frees its comms too
+    }
     if ((rc = pt_multi_scene_upload(g_multi, objs, n_objs))) return rc;
     return pt_multi_render_host(g_multi, cam, prm, out_linear, out_rgba);
 }

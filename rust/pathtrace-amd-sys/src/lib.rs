@@ -131,6 +131,7 @@ extern "C" {
     pub fn pt_multi_destroy(m: *mut PtMulti) -> c_int;
     pub fn pt_multi_device_count(m: *const PtMulti) -> u32;
     pub fn pt_multi_scene_upload(m: *mut PtMulti, objs: *const PtObject, n_objs: u32) -> c_int;
+    pub fn pt_multi_set_tuning(m: *mut PtMulti, tuning: *const PtTuning) -> c_int;
     pub fn pt_multi_render_device(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
     pub fn pt_multi_sync(m: *mut PtMulti) -> c_int;
     pub fn pt_multi_get_stats(m: *mut PtMulti, out: *mut PtStats) -> c_int;

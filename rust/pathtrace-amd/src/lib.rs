@@ -95,20 +95,29 @@ impl Renderer {
         struct Ctx<'a> {
             f: &'a mut dyn FnMut(u32, u32, &[u8]) -> bool,
             len: usize,
+            panic: Option<Box<dyn std::any::Any + Send + 'static>>,
         }
+        // A panic must not unwind through the C frames of pt_render_progressive (undefined behaviour): it is caught
+        // here, the render is asked to stop (non-zero return), and the panic resumes on the Rust side of the call.
         unsafe extern "C" fn tramp(user: *mut std::os::raw::c_void, done: u32, total: u32, rgba8: *const u8, _lin: *const f32) -> i32 {
             let c = &mut *(user as *mut Ctx);
             let px = std::slice::from_raw_parts(rgba8, c.len);
-            (c.f)(done, total, px) as i32
+            let f = &mut c.f;
+            match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| f(done, total, px))) {
+                Ok(stop) => stop as i32,
+                Err(payload) => { c.panic = Some(payload); 1 }
+            }
         }
         let band_count = params.band_count.max(1);
         let rows = unsafe { sys::pt_tile_rows(cam.height, params.band_rows, params.band_index, band_count) };
         let n = rows as usize * cam.width as usize;
         let mut film = Film { width: cam.width, rows, linear_rgb: vec![0f32; n * 3], rgba8: vec![0u8; n * 4] };
-        let mut c = Ctx { f: &mut on_frame, len: n * 4 };
-        check(unsafe {
+        let mut c = Ctx { f: &mut on_frame, len: n * 4, panic: None };
+        let rc = unsafe {
             sys::pt_render_progressive(self.ctx, cam, params, spp_step, Some(tramp), &mut c as *mut Ctx as *mut _, film.linear_rgb.as_mut_ptr(), film.rgba8.as_mut_ptr())
-        })?;
+        };
+        if let Some(payload) = c.panic.take() { std::panic::resume_unwind(payload); }
+        check(rc)?;
         Ok(film)
     }
     pub fn stats(&mut self) -> Result<Stats, Error> {

@@ -12,8 +12,7 @@ every case is rendered in both:
   * exact_math = 0 (default; hardware 1-ulp rcp/sqrt, what bench.py measures) additionally
     stays close to the f32 oracle: >= 99 % of pixels within 1e-3 relative, vertex count
     within 1e-4 (paths are the same paths, perturbed by ulps).
-OrenNayar is the one material evaluated with libdevice atan2f/cosf, so it is held to
-the tolerance bars only."""
+All four materials are bit-reproducible (OrenNayar's azimuth term is trig-free in the f32 specification)."""
 import os
 
 import numpy as np
@@ -233,7 +232,7 @@ def test_full_size_exact_mode_is_bit_identical_to_the_f32_oracle(pt, orc, gpu_ct
 _REF_CACHE = {}
 
 
-def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.01, chaotic=False, **kw):
+def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.01, chaotic=False, mean_rel=1e-3, **kw):
     """SURVEY 8(d) parity bar (iii): GPU f32 (DEFAULT arithmetic, what bench.py measures) against the f64
     reference-faithful recursive oracle at `spp` samples per pixel.
     (1) Same sample indices: the two films differ only by f32 rounding and rare branch flips -- far below the
@@ -260,7 +259,8 @@ def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.
     # image-mean relative error <= 1e-3.  In a chaotic scene f32 and f64 paths of the same sample decorrelate
     # after a few bounces, and the "same-sample" difference is then itself Monte-Carlo noise: there the bound is what (2)
     # applies to independent films, 3 sigma of the image-mean difference, where that is the larger one.
-    mean_tol = 1e-3 * ref.mean()
+    mean_tol = mean_rel * ref.mean()
+    print(f"same-sample image mean: GPU - f64 oracle = {d_same.mean():+.3e} = {d_same.mean() / ref.mean():+.2e} relative (bar {mean_rel:g})")
     if chaotic:
         mean_tol = max(mean_tol, 3.0 * np.sqrt(2.0 * (sigma[lit] ** 2).sum()) / lit.sum())
     assert abs(d_same.mean()) <= mean_tol, (d_same.mean(), ref.mean(), mean_tol)
@@ -283,7 +283,9 @@ def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.
 
 def test_convergence_at_4096_spp_shows_no_bias(pt, orc, gpu_ctx):
     """C2 (BASELINE configs[1] scene), 128 x 128, 4096 spp."""
-    lit, _ = _no_bias(pt, orc, gpu_ctx, pt.builtin_scene(2), pt.camera_new(width=128, height=128), 4096)
+    # C2 holds the same-sample image mean to 1e-4 relative (ten times inside SURVEY's 1e-3): a systematic shift from the
+    # fast-arithmetic substitutions (a = 1 sphere test, native sin/cos, roulette word from the low bits) would show here
+    lit, _ = _no_bias(pt, orc, gpu_ctx, pt.builtin_scene(2), pt.camera_new(width=128, height=128), 4096, mean_rel=1e-4)
     assert lit > 0.95
 
 

@@ -3,10 +3,11 @@
 # (never combined with trace domains other than --kernel-trace).  Output: gpurun_out/prof_<tag>/ and the summary
 # gpurun_out/prof_<tag>/roofline_<tag>.json (tools/roofline_from_profile.py), to be copied into profiles/.
 #   tools/profile_workload.sh <tag> [bench.py args, e.g. --workload c1 | --workload c4 --accel 1]
-set -e
-TAG=$1; shift
-OUT=gpurun_out/prof_$TAG
-rm -rf $OUT; mkdir -p $OUT
+set -eu
+TAG=${1:?usage: tools/profile_workload.sh <tag> [bench.py args]}; shift
+case "$TAG" in */*|.*|"") echo "bad tag: $TAG" >&2; exit 2;; esac
+OUT="gpurun_out/prof_$TAG"
+rm -rf "${OUT:?}"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
 python3 $ARGS > $OUT/bench_plain.json
