@@ -243,10 +243,11 @@ static void ray_color_batch(const PtObject* objs, uint32_t nobj, const PtRenderP
         const double* r = rays + 6 * i;
         Ray<R> ray(V3<R>((R)r[0], (R)r[1], (R)r[2]), V3<R>((R)r[3], (R)r[4], (R)r[5]));
         Draws dr{{xy[2 * i], xy[2 * i + 1]}, pp->spp_offset};
+        PhiloxSampler sm(dr);
         V3<R> c;
         if (form == FORM_ITERATIVE) c = ray_color_iter(sc, prm, ray, dr, cn);
-        else if (prm.integrator == PT_INTEGRATOR_MIS) c = ray_color_mis_rec(sc, prm, ray, 0, dr, V3<R>::one(), cn);
-        else c = ray_color_brdf_rec(sc, prm, ray, 0, dr, V3<R>::one(), cn);
+        else if (prm.integrator == PT_INTEGRATOR_MIS) c = ray_color_mis_rec(sc, prm, ray, 0, sm, V3<R>::one(), cn);
+        else c = ray_color_brdf_rec(sc, prm, ray, 0, sm, V3<R>::one(), cn);
         out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
     }
 }
@@ -364,4 +365,75 @@ extern "C" int orc_render_pixels(const PtCamera* cam, const PtObject* objs, uint
     if (precision == 64) render_pixels_impl<double>(cam, objs, nobj, p, form, xy, n, out_lin, out_samples);
     else render_pixels_impl<float>(cam, objs, nobj, p, form, xy, n, out_lin, out_samples);
     return 0;
+}
+
+// ------------------------------------------------------------------ the reference's own draw source (StdRng restated)
+// orc_render with one sequential ChaCha12 stream per pixel instead of Philox addressing: f64, recursive form.
+// Restated from the published algorithms, unverified against the rand crate (pt_oracle.hpp, StdRngStream).
+extern "C" int orc_render_stdrng(const PtCamera* pc, const PtObject* objs, uint32_t n, const PtRenderParams* pp, int threads,
+                                 double* out_lin, uint8_t* out_rgba, uint64_t* out_counters) {
+    if (!pc || !objs || !pp || pp->spp == 0) return 1;
+    Scene<double> scene = build_scene<double>(objs, n);
+    Camera<double> cam = make_camera<double>(pc);
+    Params prm = make_params(pp);
+    std::vector<uint32_t> rows = tile_rows(pc->height, pp->band_rows, pp->band_index, pp->band_count);
+    const uint32_t W = pc->width;
+    const size_t npix = rows.size() * (size_t)W;
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next{0};
+    std::vector<Counters> cns(threads);
+    auto worker = [&](int tid) {
+        for (;;) {
+            const size_t b = next.fetch_add(16);
+            if (b >= npix) break;
+            const size_t e = b + 16 < npix ? b + 16 : npix;
+            for (size_t i = b; i < e; ++i) {
+                double lin[3]; uint8_t rg[4];
+                render_pixel_stdrng(scene, cam, prm, (uint32_t)(i % W), rows[i / W], pp->spp, pp->spp_offset, lin, rg, cns[tid]);
+                if (out_lin) { out_lin[i * 3] = lin[0]; out_lin[i * 3 + 1] = lin[1]; out_lin[i * 3 + 2] = lin[2]; }
+                if (out_rgba) std::memcpy(out_rgba + i * 4, rg, 4);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (out_counters) {
+        uint64_t v = 0, s = 0, sc = 0; uint32_t md = 0;
+        for (auto& c : cns) { v += c.vertices; s += c.shadow_rays; sc += c.scans; if (c.max_depth > md) md = c.max_depth; }
+        out_counters[0] = v; out_counters[1] = s; out_counters[2] = sc; out_counters[3] = md;
+    }
+    return 0;
+}
+// per-sample radiances of listed pixels from the sequential stream (the reference's pixel diagnostics, world.rs:378-417)
+extern "C" int orc_render_pixels_stdrng(const PtCamera* pc, const PtObject* objs, uint32_t nobj, const PtRenderParams* pp,
+                                        const uint32_t* xy, uint32_t n, double* out_lin, double* out_samples) {
+    if (!pc || !objs || !pp || pp->spp == 0 || (n && !xy)) return 1;
+    Scene<double> scene = build_scene<double>(objs, nobj);
+    Camera<double> cam = make_camera<double>(pc);
+    Params prm = make_params(pp);
+    Counters cn;
+    for (uint32_t i = 0; i < n; ++i) {
+        double lin[3]; uint8_t rg[4];
+        render_pixel_stdrng(scene, cam, prm, xy[2 * i], xy[2 * i + 1], pp->spp, pp->spp_offset, lin, rg, cn,
+                            out_samples ? out_samples + (size_t)i * pp->spp * 3 : nullptr);
+        if (out_lin) std::memcpy(out_lin + 3 * (size_t)i, lin, sizeof lin);
+    }
+    return 0;
+}
+// pins of the generator itself (tests/test_rng.py)
+extern "C" void orc_chacha_block(const uint32_t in[16], int rounds, uint32_t out[16]) { chacha_block(in, rounds, out); }
+extern "C" void orc_stdrng_seed_key(uint64_t seed, uint32_t key_out[8]) { StdRngStream r(seed); std::memcpy(key_out, r.key, sizeof r.key); }
+// mode 0: n x next_u32 -> out32; 1: n x next_u64 -> out64; 2: n x random::<f64>() -> outf; 3: n x random_range(0..arg) -> out32;
+// 4: alternating next_u32 (-> out32[i]) and next_u64 (-> out64[i]): buffer-straddling reads
+extern "C" void orc_stdrng_draw(uint64_t seed, int rounds, int mode, uint32_t arg, uint32_t n, uint32_t* out32, uint64_t* out64, double* outf) {
+    StdRngStream r(seed, rounds);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (mode == 0) out32[i] = r.next_u32();
+        else if (mode == 1) out64[i] = r.next_u64();
+        else if (mode == 2) outf[i] = r.f64();
+        else if (mode == 3) out32[i] = r.range(arg);
+        else { out32[i] = r.next_u32(); out64[i] = r.next_u64(); }
+    }
 }

@@ -79,6 +79,54 @@ def render_pixels(cam, objs, params, xy, precision=F64, form=RECURSIVE):
     return lin, smp
 
 
+def render_stdrng(cam, objs, params, threads=1):
+    """orc.render(F64, RECURSIVE) drawing from the reference's own generator: one sequential StdRng (ChaCha12) stream
+    per pixel, seeded (y << 32) | x (main.rs:51-52).  Restated from the published algorithm, unverified against the
+    rand crate.  -> (linear float64[rows,W,3], rgba uint8[rows,W,4], counters dict)"""
+    rows = lib().orc_tile_rows(C.c_uint32(cam.height), C.c_uint32(params.band_rows), C.c_uint32(params.band_index),
+                               C.c_uint32(params.band_count or 1))
+    lin = np.zeros((rows, cam.width, 3), dtype=np.float64)
+    rgba = np.zeros((rows, cam.width, 4), dtype=np.uint8)
+    cnt = np.zeros(4, dtype=np.uint64)
+    rc = lib().orc_render_stdrng(C.byref(cam), objs, C.c_uint32(len(objs)), C.byref(params), C.c_int(threads), _p(lin), _p(rgba), _p(cnt))
+    if rc:
+        raise RuntimeError(f"orc_render_stdrng failed: {rc}")
+    return lin, rgba, {"vertices": int(cnt[0]), "shadow_rays": int(cnt[1]), "scans": int(cnt[2]), "max_depth": int(cnt[3])}
+
+
+def render_pixels_stdrng(cam, objs, params, xy):
+    """World::render_pixel for a pixel list from the sequential StdRng stream -> (linear float64[n,3], samples [n,spp,3])"""
+    xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+    n = xy.shape[0]
+    lin = np.zeros((n, 3), dtype=np.float64)
+    smp = np.zeros((n, params.spp, 3), dtype=np.float64)
+    rc = lib().orc_render_pixels_stdrng(C.byref(cam), objs, C.c_uint32(len(objs)), C.byref(params), _p(xy), C.c_uint32(n), _p(lin), _p(smp))
+    if rc:
+        raise RuntimeError(f"orc_render_pixels_stdrng failed: {rc}")
+    return lin, smp
+
+
+def chacha_block(state16, rounds):
+    i = (C.c_uint32 * 16)(*[int(v) for v in state16])
+    o = (C.c_uint32 * 16)()
+    lib().orc_chacha_block(i, C.c_int(rounds), o)
+    return [int(v) for v in o]
+
+
+def stdrng_seed_key(seed):
+    k = (C.c_uint32 * 8)()
+    lib().orc_stdrng_seed_key(C.c_uint64(seed), k)
+    return [int(v) for v in k]
+
+
+def stdrng_draw(seed, mode, n, arg=0, rounds=12):
+    """mode: "u32" | "u64" | "f64" | "range" (arg = n of 0..n) | "mixed" (alternating u32, u64 -> two lists)"""
+    m = {"u32": 0, "u64": 1, "f64": 2, "range": 3, "mixed": 4}[mode]
+    o32 = np.zeros(n, dtype=np.uint32); o64 = np.zeros(n, dtype=np.uint64); of = np.zeros(n, dtype=np.float64)
+    lib().orc_stdrng_draw(C.c_uint64(seed), C.c_int(rounds), C.c_int(m), C.c_uint32(arg), C.c_uint32(n), _p(o32), _p(o64), _p(of))
+    return {0: o32, 1: o64, 2: of, 3: o32, 4: (o32, o64)}[m]
+
+
 def hit_scene(objs, rays, t_min=0.001, t_max=float("inf"), precision=F64):
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     n = rays.shape[0]

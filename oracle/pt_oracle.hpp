@@ -23,6 +23,13 @@
 // addresses every draw as philox(ctr=(x, y, sample, depth), key=(block, 0)) so
 // that a wavefront may evaluate vertices in any order.
 //
+// A second draw source exists for Real=double, recursive form only: StdRngStream below restates the reference's own
+// generator (ChaCha12 behind rand's StdRng, seed_from_u64, one sequential stream per pixel) from its published
+// algorithm.  It is UNVERIFIED AGAINST THE rand CRATE (not in the tree, nothing fetched); its block function is pinned
+// by the RFC 8439 and eSTREAM/Strombergson ChaCha vectors (tests/test_rng.py).  It exists to check the Philox
+// ADDRESSING (shared surface block, roulette bits from the low 9) against something other than itself, and to make a
+// number-for-number comparison possible the day a Rust-produced luminance.csv exists (examples/luminance_diff).
+//
 // Two instantiations:
 //   Real=double : reference-faithful arithmetic (no FMA, true divisions, libm
 //                 sin/cos), recursive integrator exactly as rendering.rs:34-142.
@@ -97,6 +104,125 @@ struct Draws {
         uint32_t k[2] = {blk, 0u};                           // key = (block, 0)
         philox4x32_10(c, k, out);
     }
+};
+
+// ------------------------------------------------------------------ the reference's generator, restated
+// rand 0.9.2 `StdRng` = rand_chacha 0.9.0 `ChaCha12Rng` (Cargo.lock:1092-1118; crates absent from the tree).  Restated
+// from the published algorithms; unverified against the crates themselves:
+//   * ChaCha block function (Bernstein 2008; RFC 8439 2.3 for the 20-round form), `rounds` a parameter.  State =
+//     "expand 32-byte k" | 8 key words | 64-bit block counter (words 12, 13) | 64-bit stream id = 0 (words 14, 15).
+//   * rand_core `SeedableRng::seed_from_u64`: the 32-byte seed is 8 outputs of PCG32 (XSH-RR) run from the u64, each
+//     state advance BEFORE its output (mul 6364136223846793005, inc 11634580027462260723), little-endian.
+//   * rand_core `BlockRng`: a buffer of 64 words = 4 consecutive blocks; next_u32 = next word; next_u64 = two
+//     consecutive words, low word first (straddling a refill when one word is left).
+//   * `random::<f64>()` = (next_u64() >> 11) * 2^-53; `random_range(0..n)` for a usize range that fits u32 = one u32
+//     draw, widening multiply by n, and Canon's single bias-reducing redraw when the low half exceeds -n mod 2^32.
+inline uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+inline void chacha_block(const uint32_t in[16], int rounds, uint32_t out[16]) {
+    uint32_t x[16];
+    for (int i = 0; i < 16; ++i) x[i] = in[i];
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl32(x[d], 16);
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl32(x[b], 12);
+        x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl32(x[d], 8);
+        x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl32(x[b], 7);
+    };
+    for (int r = 0; r < rounds; r += 2) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);      // column round
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);      // diagonal round
+    }
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + in[i];
+}
+struct StdRngStream {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t buf[64];
+    uint32_t index = 64;          // 64 = buffer used up
+    int rounds = 12;
+    explicit StdRngStream(uint64_t seed, int rounds_ = 12) : rounds(rounds_) {    // seed_from_u64
+        uint64_t state = seed;
+        for (int i = 0; i < 8; ++i) {
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            const uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));    // rotate_right
+        }
+    }
+    void refill() {
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                                     key[4], key[5], key[6], key[7], (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+            chacha_block(in, rounds, buf + 16 * b);
+            ++counter;
+        }
+        index = 0;
+    }
+    uint32_t next_u32() {
+        if (index >= 64) refill();
+        return buf[index++];
+    }
+    uint64_t next_u64() {
+        if (index < 63) { const uint64_t v = ((uint64_t)buf[index + 1] << 32) | buf[index]; index += 2; return v; }
+        if (index >= 64) { refill(); index = 2; return ((uint64_t)buf[1] << 32) | buf[0]; }
+        const uint64_t lo = buf[63];
+        refill();
+        index = 1;
+        return ((uint64_t)buf[0] << 32) | lo;
+    }
+    double f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }   // [0, 1), 53 bits
+    uint32_t range(uint32_t n) {                                                        // random_range(0..n), n >= 1
+        const uint64_t m = (uint64_t)next_u32() * n;
+        uint32_t hi = (uint32_t)(m >> 32);
+        const uint32_t lo = (uint32_t)m;
+        if (lo > (uint32_t)(0u - n)) {
+            const uint32_t new_hi = (uint32_t)(((uint64_t)next_u32() * n) >> 32);
+            hi += (uint32_t)(((uint64_t)lo + new_hi) >> 32);                            // carry of lo + new_hi
+        }
+        return hi;
+    }
+};
+
+// ------------------------------------------------------------------ draw sources of the integrators
+// The integrators below pull their random numbers through one of these, in the reference's program order
+// (SURVEY Appendix A): [light index] [light r1, r2] [bsdf r1, r2] [Mirror lobe u, only if i.h > 0] [roulette u].
+//   PhiloxSampler: the build's addressing -- philox(ctr = (x, y, sample, depth), key = (block, 0)); a getter returns
+//                  the same value however often and in whatever order it is called.
+//   StreamSampler: the reference's -- every getter consumes the next draw(s) of the pixel's sequential StdRng stream.
+struct PhiloxSampler {
+    Draws dr;
+    uint32_t ds[4] = {0, 0, 0, 0}, dc[4] = {0, 0, 0, 0};
+    explicit PhiloxSampler(const Draws& d) : dr(d) {}
+    void vertex(uint32_t depth) { dr.block(depth, BLK_SURFACE, ds); dr.block(depth, BLK_CHOICE, dc); }
+    void camera(double& ox, double& oy) const { uint32_t c[4]; dr.block(DEPTH_CAMERA, 0, c); ox = u01(c[0]); oy = u01(c[1]); }
+    uint32_t light_index(uint32_t n) const { return (uint32_t)(((uint64_t)dc[DIM_LIGHT_INDEX] * n) >> 32); }
+    double light_r1() const { return u01(ds[DIM_LIGHT_R1]); }
+    double light_r2() const { return u01(ds[DIM_LIGHT_R2]); }
+    double bsdf_r1() const { return u01(ds[DIM_BSDF_R1]); }
+    double bsdf_r2() const { return u01(ds[DIM_BSDF_R2]); }
+    double lobe() const { return u01(dc[DIM_LOBE]); }
+    double roulette() const { return u01(rr_word(ds)); }
+};
+struct StreamSampler {
+    StdRngStream* rng;
+    void vertex(uint32_t) {}
+    void camera(double& ox, double& oy) { ox = rng->f64(); oy = rng->f64(); }      // world.rs:299: ox first
+    uint32_t light_index(uint32_t n) { return rng->range(n); }                     // world.rs:255
+    double light_r1() { return rng->f64(); }                                       // shape.rs:111 / :211
+    double light_r2() { return rng->f64(); }                                       // shape.rs:112 / :212
+    double bsdf_r1() { return rng->f64(); }                                        // material.rs:100, mirror.rs:42
+    double bsdf_r2() { return rng->f64(); }                                        // material.rs:101, mirror.rs:43
+    double lobe() { return rng->f64(); }                                           // mirror.rs:232
+    double roulette() { return rng->f64(); }                                       // rendering.rs:100, :246
+};
+// the raw words of a debug / fixture entry as a draw source
+struct WordSampler {
+    uint32_t w_index, w_r1, w_r2, w_b1, w_b2, w_lobe;
+    uint32_t light_index(uint32_t n) const { return (uint32_t)(((uint64_t)w_index * n) >> 32); }
+    double light_r1() const { return u01(w_r1); }
+    double light_r2() const { return u01(w_r2); }
+    double bsdf_r1() const { return u01(w_b1); }
+    double bsdf_r2() const { return u01(w_b2); }
+    double lobe() const { return u01(w_lobe); }
 };
 
 // ------------------------------------------------------------------ arithmetic modes
@@ -646,9 +772,9 @@ template <class R> inline V3<R> mirror_vndf(const Obj<R>& m, const V3<R>& view, 
 }
 template <class R> inline bool finite3(const V3<R>& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
 
-// Mirror::bsdf_pdf_sample, mirror.rs:200-305.  u_lobe is consumed only when i.h > 0.
-template <class R>
-inline void mirror_sample(const Obj<R>& m, const Ray<R>& ray, const V3<R>& n, R r1, R r2, R u_lobe, V3<R>& wo,
+// Mirror::bsdf_pdf_sample, mirror.rs:200-305.  draw_lobe() is called -- the draw consumed -- only when i.h > 0 (:232).
+template <class R, class LobeFn>
+inline void mirror_sample(const Obj<R>& m, const Ray<R>& ray, const V3<R>& n, R r1, R r2, LobeFn&& draw_lobe, V3<R>& wo,
                           V3<R>& f, R& pdf, R& cos_out) {
     V3<R> i = -ray.direction;
     R i_dot_n = i.dot(n);
@@ -663,6 +789,7 @@ inline void mirror_sample(const Obj<R>& m, const Ray<R>& ray, const V3<R>& n, R 
     bool tir = cos2_t < 0;
     R rr_f = fr.x;
     if (tir || m.metallic > R(0.99)) { rr_f = 1; fr = V3<R>(1, 1, 1); }
+    const R u_lobe = (R)draw_lobe();
     bool is_reflect = u_lobe < rr_f;
     R alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
     R n_h = n.dot(h);
@@ -763,25 +890,37 @@ inline void bsdf_pdf(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& o, const 
 }
 
 // Object::bsdf_pdf_sample (object.rs:46-54) -> Material::bsdf_pdf_sample
-// (default impl material.rs:29-40; Mirror override mirror.rs:200-305).
-// w_r1, w_r2 = the vertex's BSDF words of BLK_SURFACE, w_lobe = its lobe word of BLK_CHOICE.
-template <class R>
-inline void bsdf_pdf_sample(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& n, uint32_t w_r1, uint32_t w_r2,
-                            uint32_t w_lobe, V3<R>& wo, V3<R>& f, R& pdf, R& cos_out) {
-    R r1 = (R)u01(w_r1), r2 = (R)u01(w_r2);
+// (default impl material.rs:29-40; Mirror override mirror.rs:200-305).  Draws through `sm` in the reference's order:
+// r1, r2 (cosine sampling material.rs:100-101 / :274-275, VNDF mirror.rs:42-43), then the Mirror lobe draw if it is
+// reached; Emissive::sample_direction draws nothing (material.rs:150-158).
+template <class R, class S>
+inline void bsdf_pdf_sample_s(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& n, S& sm, V3<R>& wo, V3<R>& f, R& pdf,
+                              R& cos_out) {
     switch (ob.mat_tag) {
-        case PT_MAT_MIRROR:
-            mirror_sample(ob, ray, n, r1, r2, (R)u01(w_lobe), wo, f, pdf, cos_out);
+        case PT_MAT_MIRROR: {
+            const R r1 = (R)sm.bsdf_r1();
+            const R r2 = (R)sm.bsdf_r2();
+            mirror_sample(ob, ray, n, r1, r2, [&]() { return sm.lobe(); }, wo, f, pdf, cos_out);
             return;
+        }
         case PT_MAT_EMISSIVE:                                 // sample_direction = normal, material.rs:150-158
             wo = n;
             break;
-        default:                                              // Lambert / OrenNayar cosine sampling
+        default: {                                            // Lambert / OrenNayar cosine sampling
+            const R r1 = (R)sm.bsdf_r1();
+            const R r2 = (R)sm.bsdf_r2();
             wo = cosine_sample(n, r1, r2);
-            break;
+        } break;
     }
     bsdf_pdf(ob, ray, wo, n, f, pdf);
     cos_out = std::fmax(wo.dot(n), R(0));
+}
+// the same from raw words: w_r1, w_r2 = the vertex's BSDF words of BLK_SURFACE, w_lobe = its lobe word of BLK_CHOICE
+template <class R>
+inline void bsdf_pdf_sample(const Obj<R>& ob, const Ray<R>& ray, const V3<R>& n, uint32_t w_r1, uint32_t w_r2,
+                            uint32_t w_lobe, V3<R>& wo, V3<R>& f, R& pdf, R& cos_out) {
+    WordSampler ws{0u, 0u, 0u, w_r1, w_r2, w_lobe};
+    bsdf_pdf_sample_s(ob, ray, n, ws, wo, f, pdf, cos_out);
 }
 
 // ------------------------------------------------------------------ World (world.rs)
@@ -802,22 +941,31 @@ template <class R> inline int hit_scene(const Scene<R>& w, const Ray<R>& ray, R 
 
 template <class R> struct LightSample { V3<R> point, emission; R pdf; };   // world.rs:48-52
 
-// World::sample_light_point, world.rs:251-267.  w_index = the vertex's light-index word (BLK_CHOICE),
-// w_r1, w_r2 = its light words of BLK_SURFACE.
-// random_range(0..n): rand's widening-multiply reduction, without its rare
-// bias-rejection redraw (a second draw would break (depth,dim) addressing).
-template <class R>
-inline bool sample_light_point(const Scene<R>& w, const Hit<R>& hit, uint32_t w_index, uint32_t w_r1, uint32_t w_r2,
-                               LightSample<R>& ls) {
+// World::sample_light_point, world.rs:251-267.  Draws through `sm`: the light index (random_range(0..n), :255), then
+// the two surface draws of Shape::sample_surface_from_point (shape.rs:111-112, :211-212); nothing if there is no light.
+// PhiloxSampler / WordSampler: random_range = rand's widening multiply without its rare bias-rejection redraw (a second
+// draw would break (depth, dim) addressing); StreamSampler keeps the redraw.
+template <class R, class S>
+inline bool sample_light_point_s(const Scene<R>& w, const Hit<R>& hit, S& sm, LightSample<R>& ls, uint32_t* light_slot = nullptr) {
     if (w.lights.empty()) return false;
     uint32_t n = (uint32_t)w.lights.size();
-    uint32_t li = (uint32_t)(((uint64_t)w_index * n) >> 32);
+    const uint32_t li = sm.light_index(n);
+    if (light_slot) *light_slot = li;
     const Obj<R>& lo = w.objs[w.lights[li]];
+    const R r1 = (R)sm.light_r1();
+    const R r2 = (R)sm.light_r2();
     V3<R> normal, dir; R pdf_shape, dist;
-    shape_sample<R>(lo, hit, nullptr, (R)u01(w_r1), (R)u01(w_r2), ls.point, normal, pdf_shape, dir, dist);
+    shape_sample<R>(lo, hit, nullptr, r1, r2, ls.point, normal, pdf_shape, dir, dist);
     ls.emission = emit(lo);
     ls.pdf = pdf_shape / (R)n;
     return true;
+}
+// the same from raw words: w_index = the vertex's light-index word (BLK_CHOICE), w_r1, w_r2 = its light words of BLK_SURFACE
+template <class R>
+inline bool sample_light_point(const Scene<R>& w, const Hit<R>& hit, uint32_t w_index, uint32_t w_r1, uint32_t w_r2,
+                               LightSample<R>& ls) {
+    WordSampler ws{w_index, w_r1, w_r2, 0u, 0u, 0u};
+    return sample_light_point_s(w, hit, ws, ls);
 }
 
 // ------------------------------------------------------------------ integrators (rendering.rs)
@@ -838,9 +986,10 @@ template <class R> inline R eta_from_object(const Obj<R>& o, const Hit<R>& h) { 
     return h.front_face ? R(1) / get_eta(o) : get_eta(o);
 }
 
-// MisStrategy::ray_color, rendering.rs:34-142 -- RECURSIVE, line for line.
-template <class R>
-V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_t depth, const Draws& dr,
+// MisStrategy::ray_color, rendering.rs:34-142 -- RECURSIVE, line for line.  S = the draw source (PhiloxSampler:
+// addressed by depth; StreamSampler: the reference's sequential stream, consumed in this function's program order).
+template <class R, class S>
+V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_t depth, S& sm,
                         V3<R> throughput, Counters& cn) {
     const R tmin = (R)p.t_min;
     Hit<R> hit;
@@ -853,11 +1002,9 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
     V3<R> emitted = emit(obj);                                                     // :42
     if (emitted.length() > 0) return depth == 0 ? emitted : V3<R>::zero();         // :43-49
     V3<R> total = V3<R>::zero(), direct = V3<R>::zero();
-    uint32_t ds[4], dc[4];
-    dr.block(depth, BLK_SURFACE, ds);
-    dr.block(depth, BLK_CHOICE, dc);
+    sm.vertex(depth);
     LightSample<R> ls;
-    if (sample_light_point(w, hit, dc[DIM_LIGHT_INDEX], ds[DIM_LIGHT_R1], ds[DIM_LIGHT_R2], ls)) {   // :56
+    if (sample_light_point_s(w, hit, sm, ls)) {                                    // :56
         V3<R> to_light = ls.point - hit.point;                                     // :58
         R distance = to_light.length();
         V3<R> light_dir = to_light.normalize();
@@ -876,12 +1023,12 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
     total += direct / R(1);                                                        // :81 (NUM_LIGHT_SAMPLES=1)
     ray.eta_ratio = eta_from_object(obj, hit);                                     // :83
     V3<R> wo, bsdf; R pdf, cos_theta;
-    bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);   // :84-85
+    bsdf_pdf_sample_s(obj, ray, hit.normal, sm, wo, bsdf, pdf, cos_theta);         // :84-85
     Ray<R> scattered(hit.point, wo);                                               // :86
     scattered.eta_ratio = eta_from_object(obj, hit);                               // :87
     V3<R> next_tp = throughput * bsdf * cos_theta / pdf;                           // :89
     R rr = rr_prob(p, depth, next_tp);                                             // :91-98
-    if ((R)u01(rr_word(ds)) > rr) return V3<R>::zero();                             // :100-102 (drops `total`, Q1)
+    if ((R)sm.roulette() > rr) return V3<R>::zero();                               // :100-102: always drawn; drops `total` (Q1)
     Hit<R> h2;
     int o2 = hit_scene(w, scattered, tmin, kInf<R>(), h2);                         // :104-105
     cn.scans++;
@@ -900,7 +1047,7 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
             V3<R> le = emit(ob2);
             total += w_bsdf * bsdf * le * cos_theta / (pdf * rr);                  // :119-121
         } else {
-            V3<R> li = ray_color_mis_rec(w, p, scattered, depth + 1, dr, next_tp / rr, cn);   // :124-130
+            V3<R> li = ray_color_mis_rec(w, p, scattered, depth + 1, sm, next_tp / rr, cn);   // :124-130
             total += bsdf * li * cos_theta / (pdf * rr);                           // :131-133
         }
     }
@@ -908,8 +1055,8 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
 }
 
 // BrdfOnlyStrategy::ray_color, rendering.rs:214-265 -- recursive.
-template <class R>
-V3<R> ray_color_brdf_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_t depth, const Draws& dr,
+template <class R, class S>
+V3<R> ray_color_brdf_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_t depth, S& sm,
                          V3<R> throughput, Counters& cn) {
     const R tmin = (R)p.t_min;
     Hit<R> hit;
@@ -921,18 +1068,16 @@ V3<R> ray_color_brdf_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32
     const Obj<R>& obj = w.objs[oi];
     V3<R> emitted = emit(obj);
     if (emitted.length() > 0) return emitted;                                      // :225-227
-    uint32_t ds[4], dc[4];
-    dr.block(depth, BLK_SURFACE, ds);
-    dr.block(depth, BLK_CHOICE, dc);
+    sm.vertex(depth);
     ray.eta_ratio = eta_from_object(obj, hit);                                     // :230
     V3<R> wo, bsdf; R pdf, cos_theta;
-    bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);   // :231-232
+    bsdf_pdf_sample_s(obj, ray, hit.normal, sm, wo, bsdf, pdf, cos_theta);         // :231-232
     Ray<R> scattered(hit.point, wo);
     scattered.eta_ratio = eta_from_object(obj, hit);
     V3<R> next_tp = throughput * bsdf * cos_theta / pdf;                           // :236
     R rr = rr_prob(p, depth, next_tp);
-    if ((R)u01(rr_word(ds)) > rr) return V3<R>::zero();                             // :246-248
-    V3<R> li = ray_color_brdf_rec(w, p, scattered, depth + 1, dr, next_tp / rr, cn);
+    if ((R)sm.roulette() > rr) return V3<R>::zero();                               // :246-248
+    V3<R> li = ray_color_brdf_rec(w, p, scattered, depth + 1, sm, next_tp / rr, cn);
     return bsdf * li * cos_theta / (pdf * rr);                                     // :260
 }
 
@@ -951,6 +1096,7 @@ struct Trace { std::vector<double> rec; };
 template <class R>
 V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws& dr, Counters& cn,
                      Trace* tr = nullptr) {
+    PhiloxSampler sm(dr);     // this form retires zero-throughput paths (Q7): legal only with addressed draws
     const R tmin = (R)p.t_min;
     const bool mis = p.integrator == PT_INTEGRATOR_MIS;
     V3<R> L = V3<R>::zero(), beta = V3<R>::one();
@@ -988,13 +1134,11 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
             if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
             break;
         }
-        uint32_t ds[4], dc[4];
-        dr.block(depth, BLK_SURFACE, ds);
-        dr.block(depth, BLK_CHOICE, dc);
+        sm.vertex(depth);
         V3<R> direct = V3<R>::zero();
         if (mis) {
             LightSample<R> ls;
-            if (sample_light_point(w, hit, dc[DIM_LIGHT_INDEX], ds[DIM_LIGHT_R1], ds[DIM_LIGHT_R2], ls)) {
+            if (sample_light_point_s(w, hit, sm, ls)) {
                 V3<R> to_light = ls.point - hit.point;
                 R distance = to_light.length();
                 V3<R> light_dir = to_light.normalize();
@@ -1016,11 +1160,11 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
         R eta_here = eta_from_object(obj, hit);
         ray.eta_ratio = eta_here;
         V3<R> wo, bsdf; R pdf, cos_theta;
-        bsdf_pdf_sample(obj, ray, hit.normal, ds[DIM_BSDF_R1], ds[DIM_BSDF_R2], dc[DIM_LOBE], wo, bsdf, pdf, cos_theta);
+        bsdf_pdf_sample_s(obj, ray, hit.normal, sm, wo, bsdf, pdf, cos_theta);
         V3<R> next_tp = beta * bsdf * cos_theta / pdf;
         R rr = rr_prob(p, depth, next_tp);
-        if (T) { T[18] = pdf; T[19] = rr; T[20] = (double)u01(rr_word(ds)); }
-        if ((R)u01(rr_word(ds)) > rr) break;              // drops `direct` too (Q1)
+        if (T) { T[18] = pdf; T[19] = rr; T[20] = sm.roulette(); }
+        if ((R)sm.roulette() > rr) break;                 // drops `direct` too (Q1)
         L += beta * direct;
         if (T) { T[21] = L.x; T[22] = L.y; T[23] = L.z; }
         beta = next_tp / rr;
@@ -1050,21 +1194,7 @@ inline std::vector<uint32_t> tile_rows(uint32_t height, uint32_t band_rows, uint
 // World::render_pixel, world.rs:293-333.  The per-sample radiance is computed in
 // R; the film sum, mean, gamma and quantisation are f64 in every instantiation
 // (as in the reference, and as the device's resolve kernel does).
-template <class R>
-inline void render_pixel(const Scene<R>& w, const Camera<R>& cam, const Params& p, Form form, uint32_t x, uint32_t y,
-                         uint32_t spp, uint32_t spp_offset, double out_lin[3], uint8_t out_rgba[4], Counters& cn) {
-    double acc[3] = {0, 0, 0};
-    for (uint32_t s = 0; s < spp; ++s) {                                               // world.rs:296
-        Draws dr{{x, y}, spp_offset + s};                                              // main.rs:51
-        uint32_t dc[4];
-        dr.block(DEPTH_CAMERA, 0, dc);
-        Ray<R> ray = cam.get_ray_with_offset(x, cam.height - 1 - y, (R)u01(dc[0]), (R)u01(dc[1]));   // world.rs:297-299
-        V3<R> c;
-        if (form == FORM_ITERATIVE) c = ray_color_iter(w, p, ray, dr, cn);
-        else if (p.integrator == PT_INTEGRATOR_MIS) c = ray_color_mis_rec(w, p, ray, 0, dr, V3<R>::one(), cn);
-        else c = ray_color_brdf_rec(w, p, ray, 0, dr, V3<R>::one(), cn);
-        acc[0] += (double)c.x; acc[1] += (double)c.y; acc[2] += (double)c.z;           // world.rs:311
-    }
+inline void film_pixel(const double acc[3], uint32_t spp, double out_lin[3], uint8_t out_rgba[4]) {
     for (int k = 0; k < 3; ++k) {
         double m = acc[k] / (double)spp;                                               // world.rs:315
         out_lin[k] = m;                                                                // world.rs:318-319
@@ -1074,6 +1204,49 @@ inline void render_pixel(const Scene<R>& w, const Camera<R>& cam, const Params& 
         out_rgba[k] = (q != q) ? 0 : (uint8_t)q;                                       // `as u8`: trunc, NaN -> 0
     }
     out_rgba[3] = 255;
+}
+template <class R>
+inline void render_pixel(const Scene<R>& w, const Camera<R>& cam, const Params& p, Form form, uint32_t x, uint32_t y,
+                         uint32_t spp, uint32_t spp_offset, double out_lin[3], uint8_t out_rgba[4], Counters& cn) {
+    double acc[3] = {0, 0, 0};
+    for (uint32_t s = 0; s < spp; ++s) {                                               // world.rs:296
+        Draws dr{{x, y}, spp_offset + s};                                              // main.rs:51
+        PhiloxSampler sm(dr);
+        double ox, oy;
+        sm.camera(ox, oy);
+        Ray<R> ray = cam.get_ray_with_offset(x, cam.height - 1 - y, (R)ox, (R)oy);     // world.rs:297-299
+        V3<R> c;
+        if (form == FORM_ITERATIVE) c = ray_color_iter(w, p, ray, dr, cn);
+        else if (p.integrator == PT_INTEGRATOR_MIS) c = ray_color_mis_rec(w, p, ray, 0, sm, V3<R>::one(), cn);
+        else c = ray_color_brdf_rec(w, p, ray, 0, sm, V3<R>::one(), cn);
+        acc[0] += (double)c.x; acc[1] += (double)c.y; acc[2] += (double)c.z;           // world.rs:311
+    }
+    film_pixel(acc, spp, out_lin, out_rgba);
+}
+// The same with the reference's own draw source: ONE StdRng per pixel, seeded (y << 32) | x (main.rs:51-52), consumed
+// sequentially by all samples of the pixel (world.rs:296-312).  f64, recursive form only (the iterative form retires
+// zero-throughput paths early, which a sequential stream does not allow).  A sequential stream cannot be
+// entered in the middle: spp_offset samples are traced and dropped first (the skip-ahead of world.rs:634-652).
+// out_samples: optional, spp * 3 per-sample radiances.
+inline void render_pixel_stdrng(const Scene<double>& w, const Camera<double>& cam, const Params& p, uint32_t x, uint32_t y,
+                                uint32_t spp, uint32_t spp_offset, double out_lin[3], uint8_t out_rgba[4], Counters& cn,
+                                double* out_samples = nullptr) {
+    StdRngStream rng(((uint64_t)y << 32) | (uint64_t)x);                               // main.rs:51-52
+    StreamSampler sm{&rng};
+    double acc[3] = {0, 0, 0};
+    Counters skipped;
+    for (uint32_t s = 0; s < spp_offset + spp; ++s) {                                  // world.rs:296
+        double ox, oy;
+        sm.camera(ox, oy);                                                             // world.rs:299 (ox first)
+        Ray<double> ray = cam.get_ray_with_offset(x, cam.height - 1 - y, ox, oy);
+        Counters& c = s < spp_offset ? skipped : cn;
+        V3<double> col = p.integrator == PT_INTEGRATOR_MIS ? ray_color_mis_rec(w, p, ray, 0, sm, V3<double>::one(), c)
+                                                           : ray_color_brdf_rec(w, p, ray, 0, sm, V3<double>::one(), c);
+        if (s < spp_offset) continue;
+        if (out_samples) { double* o = out_samples + 3 * (size_t)(s - spp_offset); o[0] = col.x; o[1] = col.y; o[2] = col.z; }
+        acc[0] += col.x; acc[1] += col.y; acc[2] += col.z;                             // world.rs:311
+    }
+    film_pixel(acc, spp, out_lin, out_rgba);
 }
 
 }  // namespace orc

@@ -18,6 +18,8 @@ import os
 import numpy as np
 import pytest
 
+from nobias import independent_films_look_like_noise
+
 pytestmark = pytest.mark.gpu
 F64, F32, REC, ITER = 64, 32, 0, 1
 THREADS = min(16, os.cpu_count() or 1)
@@ -266,18 +268,7 @@ def _no_bias(pt, orc, ctx, objs, cam, spp, parts=8, same_frac=0.995, outliers=0.
     assert abs(d_same.mean()) <= mean_tol, (d_same.mean(), ref.mean(), mean_tol)
     assert np.mean(np.abs(d_same[lit]) <= 0.5 * sigma[lit]) >= same_frac, np.mean(np.abs(d_same[lit]) <= 0.5 * sigma[lit])
     # (2) independent samples: differences are noise, not bias
-    z = (other - ref)[lit] / (np.sqrt(2.0) * sigma[lit])
-    mean_sigma = np.sqrt(2.0 * (sigma[lit] ** 2).sum()) / lit.sum()            # sigma of the image-mean difference
-    assert abs((other - ref)[lit].mean()) <= 3.0 * mean_sigma, ((other - ref)[lit].mean(), mean_sigma)
-    spread = np.median(np.abs(z)) / 0.6745                                     # robust estimate of std(z), 1 for pure noise
-    assert 0.75 <= spread <= 1.35, spread
-    # both films are draws of the same estimator, so their difference is symmetric about 0 whatever the (skewed,
-    # heavy-tailed) per-pixel distribution is: a sign test on the pixels
-    pos = np.mean(z > 0)
-    assert abs(pos - 0.5) <= 3.0 * 0.5 / np.sqrt(z.size), pos
-    # sigma is itself estimated from a few parts, and a pixel whose parts missed a rare bright sample underestimates it:
-    # far outliers are bounded, not excluded
-    assert np.mean(np.abs(z) > 4.0) <= outliers, np.mean(np.abs(z) > 4.0)
+    _, spread = independent_films_look_like_noise(other, ref, sigma, outliers)
     return lit.mean(), spread
 
 

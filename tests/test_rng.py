@@ -73,3 +73,126 @@ def test_roulette_word_uses_only_bits_the_other_draws_skip(orc):
     assert hist.min() > 0.8 * len(rs) / 16 and hist.max() < 1.2 * len(rs) / 16
     for k in range(4):
         assert abs(np.corrcoef(rs, us[:, k])[0, 1]) < 0.04
+
+
+# ---------------------------------------------------------------- the reference's own generator, restated (oracle only)
+# rand 0.9.2 StdRng = ChaCha12 (Cargo.lock:1092-1118; crates absent from the tree).  The oracle's StdRngStream is
+# restated from the published algorithms and UNVERIFIED against the rand crate; what CAN be pinned here is pinned:
+# the block function against published ChaCha vectors at 20, 12 and 8 rounds, and seeding / buffering / uniform
+# mapping against an independent restatement in Python integers (below).
+def _words(hexstr):
+    b = bytes.fromhex(hexstr)
+    return [int.from_bytes(b[i:i + 4], "little") for i in range(0, len(b), 4)]
+
+
+CONST = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]          # "expand 32-byte k"
+
+
+def test_chacha_block_function_known_answers(orc):
+    # RFC 8439 section 2.3.2: key 00..1f, block counter 1, nonce 00:00:00:09 00:00:00:4a 00:00:00:00, 20 rounds
+    key = _words(bytes(range(32)).hex())
+    out = orc.chacha_block(CONST + key + [1, 0x09000000, 0x4A000000, 0], 20)
+    assert out == [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+                   0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    # all-zero key, counter and nonce (RFC 7539 A.1 #1 for 20 rounds; the ChaCha12 / ChaCha8 vectors of the
+    # Strombergson test-vector draft, TC1 256-bit key): the round count is the only difference between the three
+    zero = CONST + [0] * 12
+    assert orc.chacha_block(zero, 20) == _words(
+        "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    assert orc.chacha_block(zero, 12) == _words(
+        "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
+    assert orc.chacha_block(zero, 8) == _words(
+        "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42")
+
+
+class _PyStdRng:
+    """Independent restatement in Python integers: PCG32 seed expansion (rand_core seed_from_u64), ChaCha blocks with a
+    64-bit counter in words 12-13, a 64-word buffer (4 blocks), BlockRng's next_u32 / next_u64."""
+    M = (1 << 32) - 1
+
+    def __init__(self, seed, rounds=12):
+        state, key = seed, []
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & ((1 << 64) - 1)
+            xs = (((state >> 18) ^ state) >> 27) & self.M
+            rot = state >> 59
+            key.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & self.M)
+        self.key, self.rounds, self.counter, self.buf, self.index = key, rounds, 0, [], 64
+
+    def _block(self, ctr):
+        st = CONST + self.key + [ctr & self.M, ctr >> 32, 0, 0]
+        x = list(st)
+        rotl = lambda v, c: ((v << c) | (v >> (32 - c))) & self.M
+
+        def qr(a, b, c, d):
+            x[a] = (x[a] + x[b]) & self.M; x[d] = rotl(x[d] ^ x[a], 16)
+            x[c] = (x[c] + x[d]) & self.M; x[b] = rotl(x[b] ^ x[c], 12)
+            x[a] = (x[a] + x[b]) & self.M; x[d] = rotl(x[d] ^ x[a], 8)
+            x[c] = (x[c] + x[d]) & self.M; x[b] = rotl(x[b] ^ x[c], 7)
+        for _ in range(self.rounds // 2):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        return [(a + b) & self.M for a, b in zip(x, st)]
+
+    def _refill(self):
+        self.buf = sum((self._block(self.counter + b) for b in range(4)), [])
+        self.counter += 4
+        self.index = 0
+
+    def u32(self):
+        if self.index >= 64:
+            self._refill()
+        v = self.buf[self.index]
+        self.index += 1
+        return v
+
+    def u64(self):
+        if self.index < 63:
+            v = (self.buf[self.index + 1] << 32) | self.buf[self.index]
+            self.index += 2
+            return v
+        if self.index >= 64:
+            self._refill()
+            self.index = 2
+            return (self.buf[1] << 32) | self.buf[0]
+        lo = self.buf[63]
+        self._refill()
+        self.index = 1
+        return (self.buf[0] << 32) | lo
+
+
+def test_stdrng_stream_against_an_independent_restatement(orc):
+    for seed in (0, 1, (176 << 32) | 79, (158 << 32) | 10, (1 << 64) - 1):     # incl. the pixels world.rs:378,531 replay
+        py = _PyStdRng(seed)
+        assert orc.stdrng_seed_key(seed) == py.key
+        assert [int(v) for v in orc.stdrng_draw(seed, "u32", 200)] == [_PyStdRng.u32(py) for _ in range(200)]
+        py = _PyStdRng(seed)
+        assert [int(v) for v in orc.stdrng_draw(seed, "u64", 200)] == [py.u64() for _ in range(200)]
+        py = _PyStdRng(seed)                                   # odd alignment: u64 reads straddle the 64-word refill
+        a32, a64 = orc.stdrng_draw(seed, "mixed", 150)
+        exp = [(py.u32(), py.u64()) for _ in range(150)]
+        assert [int(v) for v in a32] == [e[0] for e in exp] and [int(v) for v in a64] == [e[1] for e in exp]
+        py = _PyStdRng(seed)                                   # random::<f64>() = (u64 >> 11) * 2^-53, in [0, 1)
+        f = orc.stdrng_draw(seed, "f64", 300)
+        assert [float(v) for v in f] == [(py.u64() >> 11) * 2.0 ** -53 for _ in range(300)]
+        assert (f >= 0).all() and (f < 1).all()
+    # the first block of seed 0 is the ChaCha12 block of the expanded key with counter 0
+    py = _PyStdRng(0)
+    assert [int(v) for v in orc.stdrng_draw(0, "u32", 16)] == orc.chacha_block(CONST + py.key + [0, 0, 0, 0], 12)
+
+
+def test_stdrng_random_range(orc):
+    """random_range(0..n): widening multiply of one u32 draw, Canon's single redraw when the low half exceeds 2^32 - n."""
+    for n in (1, 2, 3, 100):
+        py = _PyStdRng(12345)
+        exp = []
+        for _ in range(4000):
+            m = py.u32() * n
+            hi, lo = m >> 32, m & 0xFFFFFFFF
+            if lo > ((1 << 32) - n) & 0xFFFFFFFF:
+                hi += (lo + ((py.u32() * n) >> 32)) >> 32
+            exp.append(hi)
+        got = orc.stdrng_draw(12345, "range", 4000, arg=n)
+        assert [int(v) for v in got] == exp and got.max() < n
+        if n > 1:
+            assert np.bincount(got, minlength=n).min() > 0.4 * 4000 / n
