@@ -100,9 +100,10 @@ def cpu_baseline(pt, objs, width, height, spp_full, desc):
         lin, _, _ = orc.render(cam, objs, prm, orc.F64, orc.RECURSIVE, threads=threads)
         return lin.shape[0], time.perf_counter() - t0
 
-    def timed(threads, budget_s):
-        rows, dt = run(1, 64, threads)                      # probe: every 64th row x 1 spp
-        rate = rows * width / dt                            # samples / s
+    def timed(threads, budget_s, rate=None):
+        if rate is None:
+            rows, dt = run(1, 64, threads)                  # probe: every 64th row x 1 spp
+            rate = rows * width / dt                        # samples / s
         # full spp on every band_count-th row; fewer samples per pixel only if even every 64th row is too much
         band_count, spp = 64, spp_full
         for bc in (32, 16, 8, 4, 2, 1):
@@ -116,6 +117,7 @@ def cpu_baseline(pt, objs, width, height, spp_full, desc):
 
     rows, spp, band_count, dt = timed(cores, 12.0)
     samples = rows * width * spp
+    rate16 = samples / dt
     out = {
         "value": round(samples / dt / 1e6, 4),
         "unit": "Msamples/s",
@@ -126,7 +128,9 @@ def cpu_baseline(pt, objs, width, height, spp_full, desc):
                   f"3 scans per vertex), {cores} threads over pixels ({avail} CPUs visible)",
     }
     if avail > cores:
-        rows, spp, band_count, dt = timed(avail, 8.0)
+        # sized by the rate just measured, not by a probe: a 1-spp probe on hundreds of threads mostly times their start-up
+        # (and where the container's CPU quota is below the visible CPU count, more threads are slower, not faster)
+        rows, spp, band_count, dt = timed(avail, 4.0, rate16)
         out["all_cores"] = {"value": round(rows * width * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": avail,
                             "sample": f"same oracle on every visible CPU: every {band_count}th row ({rows} rows), {spp} spp in {dt:.2f} s wall"}
     else:

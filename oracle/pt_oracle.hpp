@@ -418,6 +418,7 @@ template <class R> struct Obj {
     V3<R> center; R radius;
     // triangle
     V3<R> v0, v1, v2;
+    V3<R> tn, tn1, tn2;   // f32 specification of TriangleShape::hit: plane normal and barycentric gradients (build_scene)
     // material
     V3<R> color;          // albedo / emission / Mirror.color
     R roughness, metallic, ior;
@@ -445,6 +446,18 @@ template <class R> inline Scene<R> build_scene(const PtObject* po, uint32_t n) {
             o.v0 = V3<R>((R)p.shape[0], (R)p.shape[1], (R)p.shape[2]);
             o.v1 = V3<R>((R)p.shape[3], (R)p.shape[4], (R)p.shape[5]);
             o.v2 = V3<R>((R)p.shape[6], (R)p.shape[7], (R)p.shape[8]);
+            // constants of the f32 form of TriangleShape::hit (triangle_hit): n = e1 x e2, N1 = (e2 x n)/(n.n),
+            // N2 = (n x e1)/(n.n), in f64 from the edges as R holds them, rounded to R -- what the device's upload does
+            // (ptbvh::triangle_scan_record), written independently
+            const V3<R> e1r = o.v1 - o.v0, e2r = o.v2 - o.v0;
+            const V3<double> e1((double)e1r.x, (double)e1r.y, (double)e1r.z), e2((double)e2r.x, (double)e2r.y, (double)e2r.z);
+            const V3<double> n(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x);
+            const double nn = n.x * n.x + n.y * n.y + n.z * n.z;
+            const V3<double> a(e2.y * n.z - e2.z * n.y, e2.z * n.x - e2.x * n.z, e2.x * n.y - e2.y * n.x);
+            const V3<double> b(n.y * e1.z - n.z * e1.y, n.z * e1.x - n.x * e1.z, n.x * e1.y - n.y * e1.x);
+            o.tn = V3<R>((R)n.x, (R)n.y, (R)n.z);
+            o.tn1 = V3<R>((R)(a.x / nn), (R)(a.y / nn), (R)(a.z / nn));
+            o.tn2 = V3<R>((R)(b.x / nn), (R)(b.y / nn), (R)(b.z / nn));
         }
         switch (p.mat_tag) {
             case PT_MAT_LAMBERT:
@@ -522,6 +535,25 @@ template <class R> inline bool sphere_hit(const Obj<R>& s, const Ray<R>& ray, R 
 // TriangleShape::hit, shape.rs:161-198 (Moeller-Trumbore)
 template <class R> inline bool triangle_hit(const Obj<R>& tr, const Ray<R>& ray, R t_min, R t_max, Hit<R>& out) {
     V3<R> e1 = tr.v1 - tr.v0, e2 = tr.v2 - tr.v0;
+    if (Ar<R>::kFloat) {
+        // f32 arithmetic specification (device-equivalent): the same u, v, t from per-triangle constants instead of two
+        // cross products per ray -- a = e1.(d x e2) = -(d.n), t = f e2.(s x e1) = -(s.n)/(d.n), u = (s + t d).N1,
+        // v = (s + t d).N2 -- with the reference's accept rules predicate for predicate (:169, :176, :183, :190)
+        R det = ray.direction.dot(tr.tn);
+        if (std::fabs(det) < R(1e-8)) return false;
+        V3<R> s = ray.origin - tr.v0;
+        R t = -s.dot(tr.tn) / det;
+        if (t < t_min || t > t_max) return false;
+        V3<R> p = madd(ray.direction, t, s);
+        R u = p.dot(tr.tn1);
+        if (!(u >= 0 && u <= R(1))) return false;
+        R v = p.dot(tr.tn2);
+        if (v < 0 || u + v > R(1)) return false;
+        V3<R> point = ray.at(t);
+        V3<R> outward = e1.cross(e2).normalize();
+        out = Hit<R>(point, outward, t, ray);
+        return true;
+    }
     V3<R> h = ray.direction.cross(e2);
     R a = e1.dot(h);
     if (std::fabs(a) < R(1e-8)) return false;
@@ -564,11 +596,12 @@ inline void sphere_sample(const Obj<R>& s, const Hit<R>& from, const Hit<R>* tar
     if (target) {
         point = target->point;
     } else {
-        R cos_theta, sin_theta;
+        R cos_theta, sin_theta, sin_theta_sq_f32 = 0;
         if (Ar<R>::kFloat) {
             R x = r1 * omc;                               // 1 - cos_theta
             cos_theta = R(1) - x;
-            sin_theta = std::sqrt(std::fmax(x * (R(2) - x), R(0)));   // sqrt((1-c)(1+c))
+            sin_theta_sq_f32 = std::fmax(x * (R(2) - x), R(0));       // (1-c)(1+c)
+            sin_theta = std::sqrt(sin_theta_sq_f32);
         } else {
             cos_theta = R(1) - r1 + r1 * cos_theta_max;
             sin_theta = std::sqrt(std::fmax(R(1) - cos_theta * cos_theta, R(0)));
@@ -577,19 +610,26 @@ inline void sphere_sample(const Obj<R>& s, const Hit<R>& from, const Hit<R>* tar
         Ar<R>::sincos2pi(r2, sphi, cphi);
         V3<R> w = to_center.normalize();
         if (Ar<R>::kFloat) {
-            // f32 specification: the frame as in frame_of; the direction is normalised once (Ray::new, shape.rs:128)
-            // and that unit vector serves the whole quadratic (a = 1; the reference mixes the un-normalised
-            // vector for a, half_b with the normalised one for ray.at, shape.rs:130-137); discriminant in the robust
-            // form of sphere_hit (same quantity as half_b^2 - c), clamped at 0 (unguarded sqrt).
+            // f32 specification: the frame as in frame_of; the direction is normalised once (Ray::new, shape.rs:128).
+            // The sampled point is from + t * direction, so the light direction and distance rendering.rs:58-60 derives
+            // from the point again ARE direction and t: they are returned as such (dir, dist; the f32 integrators use
+            // them), and t is the near root of the cone ray in the cone's own coordinates,
+            //     t = dc cos(theta) - sqrt(r^2 - dc^2 sin^2(theta)),  dc = |center - from|
+            // -- the same real number as the reference's quadratic on world coordinates (shape.rs:130-137), which mixes
+            // the un-normalised direction for a, half_b with the normalised one for ray.at.  Discriminant clamped at 0
+            // (unguarded sqrt).
             V3<R> u, v;
             frame_of(w, u, v);
             V3<R> direction = frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta).normalize();
-            V3<R> oc = from.point - s.center;
-            R half_b = oc.dot(direction);
-            V3<R> l = madd(direction, -half_b, oc);
-            R disc = s.radius * s.radius - l.dot(l);
-            R t = -half_b - std::sqrt(std::fmax(disc, R(0)));
+            R sin2_theta = sin_theta_sq_f32;
+            R dc = std::sqrt(distance_sq);
+            R disc = Ar<R>::mad(-distance_sq, sin2_theta, s.radius * s.radius);
+            R t = Ar<R>::mad(dc, cos_theta, -std::sqrt(std::fmax(disc, R(0))));
             point = madd(direction, t, from.point);
+            normal = (point - s.center).normalize();
+            dir = direction;
+            dist = t;
+            return;
         } else {
             V3<R> up = std::fabs(w.y) > R(0.999) ? V3<R>(1, 0, 0) : V3<R>(0, 1, 0);
             V3<R> u = up.cross(w).normalize();
@@ -638,6 +678,7 @@ inline void triangle_sample(const Obj<R>& tr, const Hit<R>& from, const Hit<R>* 
     R cos_light = std::fabs(normal.dot(-dir));
     R pdf_area = R(1) / area;
     pdf_omega = cos_light > R(1e-8) ? pdf_area * (dist * dist) / cos_light : R(1e-8);
+    if (!(dist > 0)) dir = to_light;      // as returned to the integrator: Vector3::normalize keeps a zero vector (math.rs:48-51)
 }
 
 template <class R>
@@ -939,7 +980,9 @@ template <class R> inline int hit_scene(const Scene<R>& w, const Ray<R>& ray, R 
     return hit_obj;
 }
 
-template <class R> struct LightSample { V3<R> point, emission; R pdf; };   // world.rs:48-52
+// world.rs:48-52; dir / dist: direction and distance from the shading point as the sampler itself formed them (the f32
+// specification uses them instead of deriving them from the point a second time, rendering.rs:58-60)
+template <class R> struct LightSample { V3<R> point, emission; R pdf; V3<R> dir; R dist; };
 
 // World::sample_light_point, world.rs:251-267.  Draws through `sm`: the light index (random_range(0..n), :255), then
 // the two surface draws of Shape::sample_surface_from_point (shape.rs:111-112, :211-212); nothing if there is no light.
@@ -954,8 +997,8 @@ inline bool sample_light_point_s(const Scene<R>& w, const Hit<R>& hit, S& sm, Li
     const Obj<R>& lo = w.objs[w.lights[li]];
     const R r1 = (R)sm.light_r1();
     const R r2 = (R)sm.light_r2();
-    V3<R> normal, dir; R pdf_shape, dist;
-    shape_sample<R>(lo, hit, nullptr, r1, r2, ls.point, normal, pdf_shape, dir, dist);
+    V3<R> normal; R pdf_shape;
+    shape_sample<R>(lo, hit, nullptr, r1, r2, ls.point, normal, pdf_shape, ls.dir, ls.dist);
     ls.emission = emit(lo);
     ls.pdf = pdf_shape / (R)n;
     return true;
@@ -1008,6 +1051,7 @@ V3<R> ray_color_mis_rec(const Scene<R>& w, const Params& p, Ray<R>& ray, uint32_
         V3<R> to_light = ls.point - hit.point;                                     // :58
         R distance = to_light.length();
         V3<R> light_dir = to_light.normalize();
+        if (Ar<R>::kFloat) { distance = ls.dist; light_dir = ls.dir; }             // f32 specification: from the sampler
         Ray<R> shadow(hit.point, light_dir);                                       // :62
         Hit<R> sh;
         cn.shadow_rays++; cn.scans++;
@@ -1142,6 +1186,7 @@ V3<R> ray_color_iter(const Scene<R>& w, const Params& p, Ray<R> ray, const Draws
                 V3<R> to_light = ls.point - hit.point;
                 R distance = to_light.length();
                 V3<R> light_dir = to_light.normalize();
+                if (Ar<R>::kFloat) { distance = ls.dist; light_dir = ls.dir; }     // f32 specification: from the sampler
                 Ray<R> shadow = Ray<R>::from_unit(hit.point, light_dir);
                 Hit<R> sh;
                 cn.shadow_rays++; cn.scans++;

@@ -216,7 +216,7 @@ void shape_records(const PtObject& o, float4 gather[3], float4 scan[3], int* n_s
         gather[0] = make_float4(v0[0], v0[1], v0[2], 0.f);
         gather[1] = make_float4(v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f);   // edge1, shape.rs:163
         gather[2] = make_float4(v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f);   // edge2, shape.rs:164
-        scan[0] = gather[0]; scan[1] = gather[1]; scan[2] = gather[2];
+        ptbvh::triangle_scan_record(gather[0], gather[1], gather[2], scan);       // plane + barycentric gradients (pt_bvh.h)
         *n_scan = 3;
     }
 }

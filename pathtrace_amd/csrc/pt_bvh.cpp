@@ -61,6 +61,7 @@ struct Builder {
             out.leaf_ids.push_back(o | (tri ? kTriangleBit : 0u));
             float4 r0 = shape[3 * (size_t)o], r1 = shape[3 * (size_t)o + 1], r2 = shape[3 * (size_t)o + 2];
             if (!tri) { r0.w = r0.w * r0.w; r1 = make_float4(0, 0, 0, 0); r2 = r1; }   // (c, r^2): the scan record of a sphere
+            else { float4 t[3]; triangle_scan_record(r0, r1, r2, t); r0 = t[0]; r1 = t[1]; r2 = t[2]; }
             out.leaf_rec.push_back(r0); out.leaf_rec.push_back(r1); out.leaf_rec.push_back(r2);
             out.leaf_lead.push_back(r0);
             out.leaf_prims++;

@@ -36,8 +36,8 @@ struct Built {
     float grid_min[3] = {0.f, 0.f, 0.f}, grid_cell[3] = {0.f, 0.f, 0.f};
     // Leaf slots.  Every leaf starts at a slot index that is a multiple of 4 (unused slots: id kDone), so the <= 4 ids of
     // a leaf are one aligned 16-byte load and its <= 4 lead records one 64-byte line.
-    std::vector<float4> leaf_rec;     // 3 float4 per leaf slot: sphere (c, r^2), -, - ; triangle v0, e1, e2 (the scan records)
-    std::vector<float4> leaf_lead;    // 1 float4 per leaf slot = leaf_rec[3 * slot]: all a sphere test reads (a triangle reads e1, e2 from leaf_rec)
+    std::vector<float4> leaf_rec;     // 3 float4 per leaf slot: sphere (c, r^2), -, - ; triangle: triangle_scan_record (the scan records)
+    std::vector<float4> leaf_lead;    // 1 float4 per leaf slot = leaf_rec[3 * slot]: all a sphere test reads (a triangle reads the other two from leaf_rec)
     std::vector<uint32_t> leaf_ids;   // object index of the leaf slot (| kTriangleBit)
     uint32_t leaf_prims = 0;          // slots that hold a primitive (= number of objects)
     uint32_t root = kDone;            // child code of the root
@@ -48,6 +48,25 @@ struct Built {
     // traversal order reproduces: callers refuse accel = 1 for such scenes.
     uint32_t non_finite = 0;
 };
+
+// Scan record of a triangle (what the primitive test reads; pt_kernels.hip triangle_test): the f32 specification of
+// TriangleShape::hit (shape.rs:161-192) works on the triangle's plane and two barycentric gradients instead of
+// re-deriving them per ray from the edges as Moeller-Trumbore does -- same real-number u, v, t:
+//     n  = e1 x e2                 t = -(s.n) / (d.n),  s = o - v0      (a = e1.(d x e2) = -(d.n), t = f e2.(s x e1) = f s.n)
+//     N1 = (e2 x n) / (n.n)        u = (s + t d) . N1                    (N1.e1 = 1, N1.e2 = 0, N1.n = 0)
+//     N2 = (n x e1) / (n.n)        v = (s + t d) . N2                    (N2.e2 = 1, N2.e1 = 0, N2.n = 0)
+// computed in f64 from the f32 edges and rounded to f32 (the oracle's float instantiation does the same, bit for bit).
+// Packing, 3 float4: (v0.x, v0.y, v0.z, n.x) (n.y, n.z, N1.x, N1.y) (N1.z, N2.x, N2.y, N2.z).
+inline void triangle_scan_record(const float4& v0, const float4& e1f, const float4& e2f, float4 out[3]) {
+    const double e1[3] = {e1f.x, e1f.y, e1f.z}, e2[3] = {e2f.x, e2f.y, e2f.z};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const double a[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};   // e2 x n
+    const double b[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};   // n x e1
+    out[0] = make_float4(v0.x, v0.y, v0.z, (float)n[0]);
+    out[1] = make_float4((float)n[1], (float)n[2], (float)(a[0] / nn), (float)(a[1] / nn));
+    out[2] = make_float4((float)(a[2] / nn), (float)(b[0] / nn), (float)(b[1] / nn), (float)(b[2] / nn));
+}
 
 // shape: 3 float4 per object in the gather form of pt_device.h (sphere: (c, r), (1/r,..), -; triangle: v0, e1, e2);
 // scan_w: for spheres the r^2 the scan record carries.  Throws nothing; n may be 0.

@@ -223,9 +223,15 @@ PT_DEV void frame_of(f3 n, f3& tangent, f3& bitangent) {
     bitangent = cross(n, tangent);
 }
 // SphereShape::sample_surface_from_point, shape.rs:91-145.  with_target: the MIS
-// look-ahead form (point given, no draws).
+// look-ahead form (point given, no draws; dir / dist are not produced).
+// Sampled form: dir / dist = the unit direction from `from` to the sampled point and its length -- what
+// rendering.rs:58-60 derives from the point again (to_light = point - from, length, normalize).  The f32 specification
+// takes them where they come from: the point IS from + t * direction with the unit cone direction, so
+// light_dir = direction and distance = t, and t is the near root of the cone ray in the cone's own coordinates,
+// t = dc cos(theta) - sqrt(r^2 - dc^2 sin^2(theta)) with dc = |center - from| (same real numbers as the reference's
+// quadratic, shape.rs:130-137; no second normalisation, no quadratic on world coordinates: -2 sqrt/rcp, -25 VALU).
 PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float r1, float r2, f3& point,
-                          float& pdf_omega) {
+                          float& pdf_omega, f3& dir, float& dist) {
     f3 center = mk(r0.x, r0.y, r0.z);
     float radius = r0.w;
     f3 to_center = center - from;
@@ -241,25 +247,25 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
     if (with_target) { point = target; return; }
     float x1 = r1 * omc;                                   // 1 - cos_theta  (shape.rs:114)
     float cos_theta = 1.0f - x1;
-    float sin_theta = pt_sqrt(__builtin_fmaxf(x1 * (2.0f - x1), 0.0f));   // sqrt((1-c)(1+c))
+    float sin2_theta = __builtin_fmaxf(x1 * (2.0f - x1), 0.0f);           // (1-c)(1+c)
+    float sin_theta = pt_sqrt(sin2_theta);
     float sphi, cphi;
     sincos2pi(r2, sphi, cphi);
-    f3 w = normalize(to_center);
+    float dc = pt_sqrt(distance_sq);
+    f3 w = dc > 0.0f ? to_center / dc : to_center;                        // normalize(to_center), math.rs:48-51
     f3 u, v;
     frame_of(w, u, v);
-    // normalised once (Ray::new, shape.rs:128); that unit vector serves the whole quadratic (a = 1)
-    f3 direction = normalize(frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta));
-    f3 oc = from - center;
-    float half_b = dot(oc, direction);
-    f3 l = madd(direction, -half_b, oc);                // discriminant in the robust form of sphere_test
-    float disc = radius * radius - dot(l, l);
-    // deliberate deviation: disc clamped at 0 (reference: unguarded sqrt, shape.rs:136)
-    float t = -half_b - pt_sqrt(__builtin_fmaxf(disc, 0.0f));
-    point = madd(direction, t, from);
+    // normalised once (Ray::new, shape.rs:128)
+    dir = normalize(frame3(u, sin_theta * cphi, v, sin_theta * sphi, w, cos_theta));
+    // deliberate deviation: the discriminant is clamped at 0 (reference: unguarded sqrt, shape.rs:136)
+    float disc = __builtin_fmaf(-distance_sq, sin2_theta, radius * radius);
+    dist = __builtin_fmaf(dc, cos_theta, -pt_sqrt(__builtin_fmaxf(disc, 0.0f)));
+    point = madd(dir, dist, from);
 }
-// TriangleShape::sample_surface_from_point, shape.rs:200-242
+// TriangleShape::sample_surface_from_point, shape.rs:200-242; dir / dist as above (here the reference itself forms
+// them, :218-221, and rendering.rs:58-60 forms the same values again)
 PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 target, float r1, float r2,
-                            f3& point, float& pdf_omega) {
+                            f3& point, float& pdf_omega, f3& dir, float& dist) {
     if (with_target) {
         point = target;
     } else {
@@ -282,16 +288,18 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 t
     float cos_light = __builtin_fabsf(dot(normal, -light_dir));
     float pdf_area = pt_rcp(area);
     pdf_omega = cos_light > 1e-8f ? pt_div(pdf_area * (d * d), cos_light) : 1e-8f;
+    dist = d;
+    dir = d > 0.0f ? light_dir : to_light;           // Vector3::normalize leaves a zero vector as it is (math.rs:48-51)
 }
 PT_DEV void shape_sample(const float4* __restrict__ shape, int id, uint32_t shape_tag, f3 from, bool with_target,
-                         f3 target, float r1, float r2, f3& point, float& pdf_omega) {
+                         f3 target, float r1, float r2, f3& point, float& pdf_omega, f3& dir, float& dist) {
     float4 r0 = shape[3 * id];
     if (shape_tag == SHAPE_SPHERE) {
-        sphere_sample(r0, from, with_target, target, r1, r2, point, pdf_omega);
+        sphere_sample(r0, from, with_target, target, r1, r2, point, pdf_omega, dir, dist);
     } else {
         float4 q1 = shape[3 * id + 1], q2 = shape[3 * id + 2];
         triangle_sample(mk(r0.x, r0.y, r0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), from, with_target, target,
-                        r1, r2, point, pdf_omega);
+                        r1, r2, point, pdf_omega, dir, dist);
     }
 }
 

@@ -28,7 +28,7 @@ struct BvhView {
 };
 
 struct SceneView {
-    const float4* scan;      // scan records, run-packed: sphere = 1 float4 (c, r^2); triangle = 3 float4 (v0, e1, e2)
+    const float4* scan;      // scan records, run-packed: sphere = 1 float4 (c, r^2); triangle = 3 float4 (v0, n, N1, N2: pt_bvh.h triangle_scan_record)
     const float4* shape;     // 3 float4 per object (gather form), see pt_device.h
     const float4* mat;       // 2 float4 per object
     const Run* runs;

@@ -71,21 +71,34 @@ PT_DEV void sphere_test(float4 s, f3 o, f3 d, float t_min, float& closest, int& 
     closest = c;
     id = obj;
 }
-// TriangleShape::hit (shape.rs:161-192), Moeller-Trumbore; e1, e2 precomputed.
+// TriangleShape::hit (shape.rs:161-192).  The reference runs Moeller-Trumbore per ray (two cross products, three dot
+// products with the edges); the f32 specification evaluates the same u, v, t from per-triangle constants built once at
+// upload (ptbvh::triangle_scan_record: plane normal n = e1 x e2 and the barycentric gradients N1, N2):
+//     a = e1.(d x e2) = -(d.n)        t = f e2.(s x e1) = -(s.n)/(d.n)        u = (s + t d).N1        v = (s + t d).N2
+// -- 19 instead of 30 arithmetic instructions and no cross product.  The accept rules are the reference's, predicate
+// for predicate: |a| < 1e-8 rejects (:169), u outside [0, 1] rejects, NaN included (RangeInclusive::contains, :176),
+// v < 0 or u + v > 1 rejects (:183), t outside [t_min, closest] rejects (:190); t == closest is accepted (last wins).
+// They form one conjunction, so testing the t range first (it is known first here) changes nothing.
+// Record: r0 = (v0, n.x), r1 = (n.y, n.z, N1.x, N1.y), r2 = (N1.z, N2.xyz).
 template <bool ORDERED = false, bool ANY = false>
-PT_DEV void triangle_test(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
-    f3 h = cross(d, e2);
-    float a = dot(e1, h);
-    if (__builtin_fabsf(a) < 1e-8f) return;
-    float f = pt_rcp(a);
-    f3 s = o - v0;
-    float u = f * dot(s, h);
-    if (!(u >= 0.0f && u <= 1.0f)) return;         // RangeInclusive::contains: NaN rejected
-    f3 q = cross(s, e1);
-    float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return;
-    float t = f * dot(e2, q);
+PT_DEV void triangle_test(float4 r0, float4 r1, float4 r2, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
+    const f3 n = mk(r0.w, r1.x, r1.y);
+    const float det = dot(d, n);
+    if (__builtin_fabsf(det) < 1e-8f) return;
+    const f3 s = o - mk(r0.x, r0.y, r0.z);
+    const float t = pt_div(-dot(s, n), det);
+#ifdef PT_TRI_BRANCHLESS      // measurement variant: one reject at the end instead of three early-outs
+    const f3 p = madd(d, t, s);
+    const float u = dot(p, mk(r1.z, r1.w, r2.x)), v = dot(p, mk(r2.y, r2.z, r2.w));
+    if (t < t_min || t > closest || !(u >= 0.0f && u <= 1.0f) || v < 0.0f || u + v > 1.0f) return;
+#else
     if (t < t_min || t > closest) return;
+    const f3 p = madd(d, t, s);                      // hit point relative to v0
+    const float u = dot(p, mk(r1.z, r1.w, r2.x));
+    if (!(u >= 0.0f && u <= 1.0f)) return;         // RangeInclusive::contains: NaN rejected
+    const float v = dot(p, mk(r2.y, r2.z, r2.w));
+    if (v < 0.0f || u + v > 1.0f) return;
+#endif
     if (ANY) { id = 0; return; }
     if (ORDERED && t == closest && obj < id) return;
     closest = t;
@@ -157,8 +170,7 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
     } else {
         for (uint32_t i = 0; i < n; ++i) {
             float4 a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
-            triangle_test<false, ANY>(mk(a0.x, a0.y, a0.z), mk(a1.x, a1.y, a1.z), mk(a2.x, a2.y, a2.z), o, d, t_min, closest, id,
-                          first_obj + (int)i);
+            triangle_test<false, ANY>(a0, a1, a2, o, d, t_min, closest, id, first_obj + (int)i);
         }
     }
 }
@@ -363,15 +375,16 @@ PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_
 
 // World::sample_light_point (world.rs:251-267) from `from`: w_index = the light-index word, w_r1 / w_r2 = the surface words.
 // n_lights > 0.
+// dir / dist: unit direction and distance from `from` to the point (rendering.rs:58-60), from the sampler itself.
 template <bool DIFFUSE>
 PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, uint32_t w_r1, uint32_t w_r2, f3& point,
-                               int& lobj, f3& emission, float& pdf) {
+                               int& lobj, f3& emission, float& pdf, f3& dir, float& dist) {
     const uint32_t li = __umulhi(w_index, sc.n_lights);                           // random_range(0..n), world.rs:255
     lobj = (int)sc.lights[li];
     const Mat lm = load_mat(sc.mat, lobj);
     if (DIFFUSE) __builtin_assume(lm.tag <= MAT_EMISSIVE);
     float pdf_shape;
-    shape_sample(sc.shape, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape);
+    shape_sample(sc.shape, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape, dir, dist);
     emission = lm.color;                                                          // world.rs:259
     pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);  // world.rs:260 (x/1 == x)
 }
@@ -399,8 +412,8 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
             if (MIS && p.depth != 0u) {
                 // emitter reached by a BSDF-sampled ray: its MIS weight (vertex_end) is against the light pdf of
                 // this point seen from the previous vertex = this ray's origin (rendering.rs:107-116)
-                f3 sp;
-                shape_sample(sc.shape, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, v.emit_pdf_shape);
+                f3 sp, sd; float sl;
+                shape_sample(sc.shape, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, v.emit_pdf_shape, sd, sl);
             }
             v.alive = false;
         }
@@ -423,10 +436,9 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
                 philox4x32_10(kx, py, sample, p.depth, BLK_CHOICE, 0u, dc);
                 w_index = dc[0]; v.w_lobe = dc[1];
             }
-            f3 lp;
-            sample_light_point<DIFFUSE>(sc, v.hit.point, w_index, ds[0], ds[1], lp, v.light_obj, v.ls_emission, v.ls_pdf);
-            f3 to_light = lp - v.hit.point;                                       // rendering.rs:58-60
-            v.light_dir = normalize_len(to_light, v.distance);
+            f3 lp;                                                                // rendering.rs:58-60: direction and distance
+            sample_light_point<DIFFUSE>(sc, v.hit.point, w_index, ds[0], ds[1], lp, v.light_obj, v.ls_emission, v.ls_pdf,
+                                        v.light_dir, v.distance);                 // to the point, from the sampler itself
             v.need_shadow = true;
         }
     }
@@ -1028,8 +1040,7 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                             } else {
                                 const float4* rec = sc.bvh.rec + 3u * (first + i);
                                 const float4 r1 = rec[1], r2 = rec[2];
-                                triangle_test<true>(mk(r0[i].x, r0[i].y, r0[i].z), mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), o, d,
-                                                    t_min, closest, id, (int)(w[i] & 0x7FFFFFFFu));
+                                triangle_test<true>(r0[i], r1, r2, o, d, t_min, closest, id, (int)(w[i] & 0x7FFFFFFFu));
                             }
                         }
                     }
@@ -1400,15 +1411,18 @@ __global__ void __launch_bounds__(kBlock) k_debug_fn(DebugFnArgs a) {
     } else if (a.op == kFnShapeSample) {
         const Mat m = load_mat(sc.mat, (int)a.obj);
         const f3 from = mk(in[0], in[1], in[2]);
-        f3 point; float pdf;
-        shape_sample(sc.shape, (int)a.obj, m.shape_tag, from, in[8] != 0.0f, mk(in[3], in[4], in[5]), in[6], in[7], point, pdf);
-        const f3 to_light = point - from;
-        const f3 dir = normalize(to_light);
+        f3 point, dir = mk(0.f, 0.f, 0.f); float pdf, dist = 0.0f;
+        const bool with_target = in[8] != 0.0f;
+        shape_sample(sc.shape, (int)a.obj, m.shape_tag, from, with_target, mk(in[3], in[4], in[5]), in[6], in[7], point, pdf, dir, dist);
+        if (with_target) {                   // look-ahead form: the sampler produces no direction; report the point's
+            const f3 to_light = point - from;
+            dir = normalize(to_light); dist = length(to_light);
+        }
         out[0] = point.x; out[1] = point.y; out[2] = point.z; out[3] = pdf;
-        out[4] = dir.x; out[5] = dir.y; out[6] = dir.z; out[7] = length(to_light);
+        out[4] = dir.x; out[5] = dir.y; out[6] = dir.z; out[7] = dist;
     } else if (a.op == kFnLightPoint) {
-        f3 point = mk(0.f, 0.f, 0.f), le = point; float pdf = 0.0f; int lobj = -1;
-        if (sc.n_lights > 0u) sample_light_point<false>(sc, mk(in[0], in[1], in[2]), w[0], w[1], w[2], point, lobj, le, pdf);
+        f3 point = mk(0.f, 0.f, 0.f), le = point, ld = point; float pdf = 0.0f, ll = 0.0f; int lobj = -1;
+        if (sc.n_lights > 0u) sample_light_point<false>(sc, mk(in[0], in[1], in[2]), w[0], w[1], w[2], point, lobj, le, pdf, ld, ll);
         out[0] = point.x; out[1] = point.y; out[2] = point.z; out[3] = le.x; out[4] = le.y; out[5] = le.z;
         out[6] = pdf; out[7] = (float)lobj;
     } else if (a.op == kFnCameraRay) {
