@@ -58,7 +58,7 @@ BYTES_PER_SAMPLE = 64       # the fused kernel never makes those round trips: in
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
 VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (= the f32 MFMA rate)
 F_SPHERE, F_TRIANGLE, F_SHADE = 23, 51, 200     # flops per primitive test / per shaded vertex (Lambert)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 
 
 def launch_mode(gpus, env, force_dist=False, force_multi=False):
@@ -148,7 +148,7 @@ def cpu_baseline(pt, objs, width, height, spp_full, desc):
 
 def profile_summary(world, workload, accel):
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 passes of THIS command
-    (profiles/r02/roofline_<workload>[_bvh].json, written by tools/profile_workload.sh on the GPU box).  PMC counters
+    (profiles/r03/roofline_<workload>[_bvh].json, written by tools/profile_workload.sh on the GPU box).  PMC counters
     cannot be read from inside this process, so these are the last profiled values, tagged with their source file;
     None when no profile of this exact workload exists (or N > 1)."""
     if world != 1:

@@ -89,7 +89,8 @@ extern "C" int orc_render(const PtCamera* cam, const PtObject* objs, uint32_t n,
     return render_impl<float>(cam, objs, n, p, form, threads, out_lin, out_rgba, out_counters);
 }
 
-extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+extern "C" void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) { philox4x32(ctr, key, out, rounds); }
+extern "C" int orc_draw_rounds(void) { return kDrawRounds; }
 extern "C" double orc_u01(uint32_t r) { return u01(r); }
 extern "C" uint32_t orc_rr_word(const uint32_t ds[4]) { return rr_word(ds); }
 

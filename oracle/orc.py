@@ -32,11 +32,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=None):
+    """Philox4x32 with `rounds` rounds; default = the round count of the render draws (orc_draw_rounds)."""
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().orc_philox4x32_10(c, k, o)
+    lib().orc_philox4x32(c, k, C.c_int(lib().orc_draw_rounds() if rounds is None else rounds), o)
     return [int(x) for x in o]
 
 

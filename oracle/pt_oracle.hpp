@@ -10,7 +10,7 @@
 // vector for the integrator.  What IS pinned:
 //   * Vector3 arithmetic   <- the 18 unit tests of src/math.rs:246-418
 //                             (tests/test_oracle_math.py restates every one);
-//   * the generator        <- Philox4x32-10, Random123 known-answer vectors
+//   * the generator        <- Philox4x32 (7 rounds for the render draws), Random123 known-answer vectors
 //                             (tests/test_rng.py).
 //   * everything else (intersection, sampling, BSDFs, integrator) is pinned
 //     only by source-faithfulness of this restatement: "parity unpinned" in the
@@ -53,13 +53,16 @@
 namespace orc {
 
 // ------------------------------------------------------------------ Philox
-// Philox4x32-10 (Salmon et al., SC'11; Random123).  KATs in tests/test_rng.py.
-inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+// Philox4x32-R (Salmon et al., SC'11; Random123), R = `rounds`.  KATs in tests/test_rng.py: the three Random123 vectors
+// at R = 10 and the zero-input one at R = 7.  The render draws use kDrawRounds = 7, the paper's Crush-resistant minimum
+// (its Table 2), like the device (pt_device.h PT_PHILOX_ROUNDS).
+constexpr int kDrawRounds = 7;
+inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds = 10) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0;
         uint64_t p1 = (uint64_t)M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -102,7 +105,7 @@ struct Draws {
     void block(uint32_t depth, uint32_t blk, uint32_t out[4]) const {
         uint32_t c[4] = {key[0], key[1], sample, depth};     // counter = (x, y, sample, depth)
         uint32_t k[2] = {blk, 0u};                           // key = (block, 0)
-        philox4x32_10(c, k, out);
+        philox4x32(c, k, out, kDrawRounds);
     }
 };
 

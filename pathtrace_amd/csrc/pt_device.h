@@ -112,13 +112,19 @@ PT_DEV void sincos2pi(float u, float& s, float& c) {
 }
 
 // ------------------------------------------------------------------ counter RNG
-// Philox4x32-10 (Random123).  ctr = (x, y, sample, depth) -- (x, y) = the two words of the reference's per-pixel seed
-// (y<<32)|x (src/main.rs:51) --, key = (block, 0): the key is a literal at every call, so the ten round keys are
+// Philox4x32-R (Random123; Salmon et al., SC'11), the round count a compile-time parameter.  The render draws use
+// R = 7 -- the paper's "Crush-resistant minimum" (its Table 2: Philox4x32-7 passes SmallCrush, Crush and BigCrush; 10 is
+// the default with a safety margin) -- since round 3: three rounds less are 24 VALU instructions per call, C2 -2 % (same-box
+// A/B, profiles/r03/).  The round function is pinned by the three Random123 known answers at R = 10 and the zero-input
+// one at R = 7 (tests/test_rng.py, through the oracle's independent copy; the device copy is compared bit for bit with the
+// oracle by every exact-mode parity test).
+// ctr = (x, y, sample, depth) -- (x, y) = the two words of the reference's per-pixel seed
+// (y<<32)|x (src/main.rs:51) --, key = (block, 0): the key is a literal at every call, so the round keys are
 // constants and the key schedule costs no instruction (with the pixel in the key it was 20 VALU adds per call).
 #ifndef PT_PHILOX_ROUNDS
-#define PT_PHILOX_ROUNDS 10
+#define PT_PHILOX_ROUNDS 7
 #endif
-PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+PT_DEV void philox4x32_draw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                           uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
@@ -140,8 +146,8 @@ PT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 // low 9 bits of words 0 and 1, bits 8..4 of word 2: vertex_begin, oracle rr_word()).  BLK_CHOICE is generated only
 // where it can decide something -- more than one light, or a Mirror surface -- so a vertex of a diffuse one-light scene
 // costs ONE Philox call at every depth.
-// This addressing -- ctr (x, y, sample, depth), key (block, 0), the word assignment above, camera jitter at depth
-// 0xFFFFFFFF -- is part of the ABI since round 3: spp_offset resume, pt_render_pixels replays and any archived film
+// This addressing -- 7 rounds, ctr (x, y, sample, depth), key (block, 0), the word assignment above, camera jitter at
+// depth 0xFFFFFFFF -- is part of the ABI since round 3: spp_offset resume, pt_render_pixels replays and any archived film
 // depend on it (DESIGN.md 1 "RNG").
 enum { BLK_SURFACE = 0, BLK_CHOICE = 1 };
 constexpr uint32_t kDepthCamera = 0xFFFFFFFFu;

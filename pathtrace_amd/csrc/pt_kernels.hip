@@ -361,7 +361,7 @@ PT_DEV PathState parked_state() {
 // Camera::get_ray_with_offset for sample `sample` of pixel (px, py) (camera.rs:139-147; jitter draws world.rs:299)
 PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_t py, f3& o, f3& d) {
     uint32_t dc[4];
-    philox4x32_10(px, py, sample, kDepthCamera, BLK_SURFACE, 0u, dc);
+    philox4x32_draw(px, py, sample, kDepthCamera, BLK_SURFACE, 0u, dc);
     float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
     float u = pt_div((float)px + ox, (float)(cam.width - 1u));               // camera.rs:140
     float v = pt_div((float)(cam.height - 1u - py) + oy, (float)(cam.height - 1u));   // world.rs:299 y flip
@@ -426,14 +426,14 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
     v.w_bsdf1 = v.w_bsdf2 = v.w_lobe = v.w_rr = 0u;
     if (v.alive) {
         uint32_t ds[4];
-        philox4x32_10(kx, py, sample, p.depth, BLK_SURFACE, 0u, ds);
+        philox4x32_draw(kx, py, sample, p.depth, BLK_SURFACE, 0u, ds);
         v.w_bsdf1 = ds[2]; v.w_bsdf2 = ds[3];
         v.w_rr = (ds[0] << 23) | ((ds[1] & 0x1FFu) << 14) | ((ds[2] & 0x1FFu) << 5);   // roulette word: the bits of the block u01() skips
         if (MIS && sc.n_lights > 0u) {
             uint32_t w_index = 0u;                                                // umulhi(u, 1) = 0: one light needs no draw
             if (sc.n_lights > 1u) {
                 uint32_t dc[4];
-                philox4x32_10(kx, py, sample, p.depth, BLK_CHOICE, 0u, dc);
+                philox4x32_draw(kx, py, sample, p.depth, BLK_CHOICE, 0u, dc);
                 w_index = dc[0]; v.w_lobe = dc[1];
             }
             f3 lp;                                                                // rendering.rs:58-60: direction and distance
@@ -485,7 +485,7 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
         uint32_t w_lobe = v.w_lobe, w_rr = v.w_rr;
         if (!(MIS && n_lights > 1u) && v.m.tag == MAT_MIRROR) {
             uint32_t dc[4];
-            philox4x32_10(kx, py, sample, p.depth, BLK_CHOICE, 0u, dc);
+            philox4x32_draw(kx, py, sample, p.depth, BLK_CHOICE, 0u, dc);
             w_lobe = dc[1];
         }
         float eta_mat = v.m.tag == MAT_MIRROR ? v.m.ior : 1.0f;               // get_eta, material.rs:50 / mirror.rs:317
@@ -1429,7 +1429,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_fn(DebugFnArgs a) {
         f3 o, d;
         camera_ray(a.cam, w[2], w[0], w[1], o, d);
         uint32_t dc[4];
-        philox4x32_10(w[0], w[1], w[2], kDepthCamera, BLK_SURFACE, 0u, dc);
+        philox4x32_draw(w[0], w[1], w[2], kDepthCamera, BLK_SURFACE, 0u, dc);
         out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z;
         out[6] = u01(dc[0]); out[7] = u01(dc[1]);
     }

@@ -18,7 +18,10 @@ def test_recursive_equals_iterative_f64(pt, orc, scene, arg, integ):
     a, ra, ca = orc.render(cam, objs, prm, F64, REC, 4)
     b, rb, cb = orc.render(cam, objs, prm, F64, ITER, 4)
     assert np.allclose(a, b, rtol=1e-11, atol=1e-13)
-    assert np.array_equal(ra, rb)
+    # the truncating u8 of two linear values 1e-11 apart can differ where sqrt(v) * 255.999 straddles an integer: a tie,
+    # at most a channel or two per image, one LSB
+    dq = np.abs(ra.astype(np.int16) - rb.astype(np.int16))
+    assert dq.max() <= 1 and np.count_nonzero(dq) <= 2
     # the recursive form keeps walking beta == 0 paths, so it can only visit MORE vertices
     assert ca["vertices"] >= cb["vertices"] and ca["max_depth"] == cb["max_depth"]
     if scene != 1:     # no Mirror => no zero-throughput paths => identical vertex sets
