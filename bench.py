@@ -180,7 +180,7 @@ def main(argv=None):
                          "2 = PT_ACCEL_AUTO, the product default (the BVH for C4-sized scenes)")
     ap.add_argument("--cont-workgroups", type=int, default=0, help="PtTuning.cont_workgroups (0 = library default)")
     ap.add_argument("--export-below", type=int, default=0, help="PtTuning.export_below (0 = library default)")
-    ap.add_argument("--level0-form", type=int, default=0, help="PtTuning.level0_form (0 = library default, 1 = queue form, 2 = regenerating form)")
+    ap.add_argument("--level0-form", type=int, default=0, help="PtTuning.level0_form (0 = library default, 1 = queue form, 2 = regenerating form, 3 = regenerating form with batched Mirror vertices)")
     ap.add_argument("--regen-workgroups", type=int, default=0, help="PtTuning.regen_workgroups (0 = library default)")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (64*N spp) instead of the strong-scaling default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -340,7 +340,10 @@ def main(argv=None):
             # large batches over a scene in LDS: the regenerating form where the library takes it (pt_api.cpp: diffuse scenes
             # by default, PtTuning.level0_form), the queue form otherwise
             big = acc["samples"] / n_stat / max(p_launches, 1) > (1 << 22)
-            if big and (args.level0_form == 2 or (args.level0_form == 0 and diffuse)):
+            n_mirror = sum(1 for o in objs if o.mat_tag == 2)
+            if big and (args.level0_form == 3 or (args.level0_form == 0 and not diffuse and 0 < 2 * n_mirror <= len(objs))):
+                kernel = "k_paths_regen_split<MIS> (regenerating form, the Mirror vertices of a wave shaded in batches of 64)"
+            elif big and (args.level0_form == 2 or (args.level0_form == 0 and diffuse)):
                 kernel = "k_paths_regen<MIS, %s>" % ("DIFFUSE" if diffuse else "generic")
             else:
                 kernel = "k_paths<kModeLds, MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")

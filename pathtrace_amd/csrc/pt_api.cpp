@@ -77,6 +77,10 @@ constexpr uint32_t kContGrid = 1024;
 #endif
 constexpr uint32_t kStatsWords = 16;            // 8 x u64 render statistics at the front of the counter buffer
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
+#ifndef PT_SPLIT_BY_DEFAULT
+#define PT_SPLIT_BY_DEFAULT 1
+#endif
+constexpr bool kSplitByDefault = PT_SPLIT_BY_DEFAULT != 0;   // scenes with a minority of Mirror objects: k_paths_regen_split (else the queue form)
 constexpr uint32_t kRegenStatic16 = 4;         // k_paths_regen: sixteenths of a batch's chunks dealt round-robin, the rest by the counters
 constexpr uint32_t kRegenExportBelow = PT_REGEN_EXPORT;  // ... and its waves hand over once the batch is used up and fewer paths than this are alive
                                                // (1: they run dry themselves and no continuation launch follows)
@@ -131,7 +135,9 @@ struct PtContext {
     bool bvh_refused = false;         // the scene has a non-finite object: PT_ACCEL_AUTO stays with the linear scan
     bool auto_bvh = false;            // PT_ACCEL_AUTO would take the BVH for this scene (size rule above)
     uint32_t bvh_depth = 0;
+    bool split_ok = false;            // a minority of the objects is Mirror: the regenerating form that batches their vertices pays
     // wavefront state
+    DevBuf<float4> xchg;              // k_paths_regen_split: exchange stacks + parking area of every wave
     DevBuf<float4> queue[4];
     DevBuf<float4> bvh_aux, bvh_sray[2];   // accel = 1: per-slot scratch of the staged passes (k_paths_bvh)
     DevBuf<float4> ovf[2][2][4];      // overflow queues of the tail hand-off: per batch parity: leftover count, chunk counters (kCountStride)[plane]
@@ -452,6 +458,14 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     c->view.diffuse_only = 1u;
     for (uint32_t i = 0; i < n; ++i)
         if (objs[i].mat_tag != PT_MAT_LAMBERT && objs[i].mat_tag != PT_MAT_EMISSIVE) c->view.diffuse_only = 0u;
+    {   // k_paths_regen_split sets the Mirror vertices aside: worth it while they are the exception
+        uint32_t n_mirror = 0;
+        for (uint32_t i = 0; i < n; ++i) n_mirror += objs[i].mat_tag == PT_MAT_MIRROR;
+        c->split_ok = n_mirror != 0 && 2 * n_mirror <= n;
+        c->view.no_oren_nayar = 1u;
+        for (uint32_t i = 0; i < n; ++i)
+            if (objs[i].mat_tag == PT_MAT_OREN_NAYAR) c->view.no_oren_nayar = 0u;
+    }
     c->view.bvh = ptk::BvhView{};
     c->has_bvh = false;
     c->bvh_refused = false;
@@ -508,8 +522,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (!list && (cam->width > 65535u || tile_rows > 65535u))   // (tile row, x) share one word of the path state
         return fail(PT_ERR_UNSUPPORTED, "tile %ux%llu: width and tile rows must be < 65536", cam->width, (unsigned long long)tile_rows);
     // scene / job that can take the regenerating level-0 kernel (decided below, once the batch size is known)
-    const bool regen_scene = (c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && c->view.diffuse_only)) && !list && !prm->accel &&
-                             c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
+    // level0_form 3 / default for scenes with a minority of Mirror objects: the regenerating form with the Mirror vertices batched
+    const bool lds_job = !list && !prm->accel && c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
+    const bool split = lds_job && (c->tuning.level0_form == 3 || (c->tuning.level0_form == 0 && c->split_ok && kSplitByDefault));
+    const bool regen_scene = split || ((c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && c->view.diffuse_only)) && lds_job);
     uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : (regen_scene ? kDefaultMaxPathsRegen : kDefaultMaxPaths);
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)
@@ -546,7 +562,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // wave there, and the divergence costs what the form saves -- C1 12.40 vs 12.21 ms.)
     const bool regen = regen_scene && hand_off;
     const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups :
-                                c->n_cus * (c->view.diffuse_only ? ptk::kRegenWavesDiffuse : ptk::kRegenWavesGeneric));
+                                c->n_cus * (split ? ptk::kRegenWavesSplit : c->view.diffuse_only ? ptk::kRegenWavesDiffuse : ptk::kRegenWavesGeneric));
     const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
     const uint32_t nw_cont = cont_grid * kWavesPerBlock;
     // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup
@@ -559,7 +575,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // (Not beside a regenerating level-0 launch: its waves hold every wave slot of the device for the whole launch, and
     // a tail that has to squeeze in beside them stretches both -- C3 8 900 Msamples/s overlapped, 10 220 in order; with
     // only the 23-VGPR resolve kernel beside it, which would fit: 8 590 against 10 780.)
-    const uint32_t regen_export = c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;
+    const uint32_t regen_export = split ? 1u : c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;   // the split form has no hand-over
     const bool overlap = n_batches > 1 && !regen;
 
     int rc;
@@ -569,6 +585,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (prm->accel && ((rc = c->bvh_aux.ensure(q_slots)) || (rc = c->bvh_sray[0].ensure(q_slots)) ||
                        (rc = c->bvh_sray[1].ensure(q_slots))))
         return rc;
+    if (regen && split && (rc = c->xchg.ensure((size_t)regen_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave))) return rc;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
     if (overlap && hand_off)
@@ -666,8 +683,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             }
             a.ovf_out_count = d_count;
             a.chunk_counter = nullptr;
+            a.xchg = nullptr;
             if (level == 0 && regen) {
                 a.chunk_counter = d_count + ptk::kRegenCounterStride;
+                if (split) a.xchg = c->xchg.p;
                 a.export_below = regen_export;
                 g = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
                 // the first kRegenStatic16 / 16 of the chunks are dealt statically

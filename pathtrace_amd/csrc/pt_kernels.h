@@ -40,6 +40,7 @@ struct SceneView {
     uint32_t scan_f4;        // float4 count of `scan`
     uint32_t n_runs, n_objs, n_lights;
     uint32_t diffuse_only;   // every material is Lambertian or emissive: kernels without the GGX / OrenNayar code
+    uint32_t no_oren_nayar;  // no OrenNayar surface (k_paths_regen_split: its plain iterations are then the diffuse-only code)
     BvhView bvh;             // valid only for launches with accel != 0
 };
 
@@ -81,6 +82,9 @@ struct BounceArgs {
     // waves take the batch's 64-path chunks from this counter (zeroed before the launch) and export what is alive
     // when it runs out
     uint32_t* chunk_counter;
+    // non-null (with chunk_counter): the regenerating form that batches Mirror vertices (k_paths_regen_split); per wave of the
+    // launch kXqF4PerWave float4 of exchange stacks + parking area
+    float4* xchg;
     uint32_t regen_static;    // chunks dealt round-robin to the waves (a multiple of the launch's wave count); the rest by the counters
     uint32_t src_mode;        // 0: pass 0 generates camera rays, 1: pass 0 reads ovf_in
     uint32_t export_below;    // >= 1; 1 = never export (a wave runs until its segment is empty)
@@ -132,7 +136,12 @@ constexpr uint32_t kBvhStack = 24;         // traversal stack entries per lane, 
 #ifndef PT_REGEN_WAVES_DIFFUSE
 #define PT_REGEN_WAVES_DIFFUSE 6
 #endif
-constexpr uint32_t kRegenWavesDiffuse = PT_REGEN_WAVES_DIFFUSE, kRegenWavesGeneric = 5;
+#ifndef PT_REGEN_WAVES_SPLIT
+#define PT_REGEN_WAVES_SPLIT 5
+#endif
+constexpr uint32_t kRegenWavesDiffuse = PT_REGEN_WAVES_DIFFUSE, kRegenWavesGeneric = 5, kRegenWavesSplit = PT_REGEN_WAVES_SPLIT;
+// k_paths_regen_split: float4 of exchange memory per wave of the launch (128 stack entries of 5 float4; 64 parking and 64 staging slots of 4)
+constexpr uint32_t kRegenSplitF4PerWave = 128u * 5u + 2u * 64u * 4u;
 // chunk counters of k_paths_regen: chunk_counter[c * kRegenCounterStride], c < kRegenCounters (256 bytes apart)
 constexpr uint32_t kRegenCounters = 8, kRegenCounterStride = 64;
 void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);

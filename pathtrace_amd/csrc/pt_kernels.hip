@@ -376,13 +376,24 @@ PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_
 // World::sample_light_point (world.rs:251-267) from `from`: w_index = the light-index word, w_r1 / w_r2 = the surface words.
 // n_lights > 0.
 // dir / dist: unit direction and distance from `from` to the point (rendering.rs:58-60), from the sampler itself.
-template <bool DIFFUSE>
+// Material sets a kernel (or a part of one) is compiled for: vertex_begin / vertex_end / sample_light_point take one as
+// their second template argument (bool DIFFUSE converts: false = every material, true = Lambertian + emissive only).
+//   kMatsAll       every material
+//   kMatsDiffuse   Lambertian and emissive only (scene property, decided at pt_scene_upload): no GGX, no OrenNayar code
+//   kMatsNoMirror  everything but Mirror (the plain iterations of k_paths_regen_split, which hand Mirror vertices on)
+constexpr int kMatsAll = 0, kMatsDiffuse = 1, kMatsNoMirror = 2;
+template <int MATS>
+PT_DEV void assume_mats(uint32_t tag) {
+    if (MATS == kMatsDiffuse) __builtin_assume(tag <= MAT_EMISSIVE);
+    if (MATS == kMatsNoMirror) __builtin_assume(tag != MAT_MIRROR);
+}
+template <int DIFFUSE>
 PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, uint32_t w_r1, uint32_t w_r2, f3& point,
                                int& lobj, f3& emission, float& pdf, f3& dir, float& dist) {
     const uint32_t li = __umulhi(w_index, sc.n_lights);                           // random_range(0..n), world.rs:255
     lobj = (int)sc.lights[li];
     const Mat lm = load_mat(sc.mat, lobj);
-    if (DIFFUSE) __builtin_assume(lm.tag <= MAT_EMISSIVE);
+    assume_mats<DIFFUSE>(lm.tag);
     float pdf_shape;
     shape_sample(sc.shape, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape, dir, dist);
     emission = lm.color;                                                          // world.rs:259
@@ -394,7 +405,7 @@ PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, ui
 // DIFFUSE: the scene has Lambertian and emissive materials only (decided at pt_scene_upload); the GGX and
 // OrenNayar code is then compiled out of the kernel (same results; smaller code, no spills at 6 waves/SIMD: C2 +2 %).
 // (kx, py) = the pixel's RNG key (main.rs:51); it is the path's film position except in pixel-list renders.
-template <bool MIS, bool DIFFUSE>
+template <bool MIS, int DIFFUSE>
 PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, float t, uint32_t sample, uint32_t kx,
                          uint32_t py, Vertex& v) {
     v.alive = active && id >= 0;
@@ -405,7 +416,7 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
     v.m.roughness = 0.f; v.m.metallic = 0.f; v.m.ior = 1.f; v.m.on_a = 1.f; v.m.on_b = 0.f;
     if (v.alive) {
         v.m = load_mat(sc.mat, id);
-        if (DIFFUSE) __builtin_assume(v.m.tag <= MAT_EMISSIVE);
+        assume_mats<DIFFUSE>(v.m.tag);
         v.hit = finish_hit(sc.shape, id, v.m.shape_tag, p.o, p.d, t);
         if (v.m.emits) {
             v.hit_emitter = true;
@@ -449,7 +460,7 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
 // REMAT (scene in LDS): the material of the hit object and the light's emission are read again here instead of
 // being carried across the visibility scan -- two broadcast LDS reads instead of ~6 live registers, which is what
 // keeps the kernel at 80 VGPRs without spills.
-template <bool MIS, bool DIFFUSE, bool REMAT>
+template <bool MIS, int DIFFUSE, bool REMAT>
 PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool visible, uint32_t sample, uint32_t kx,
                        uint32_t py, uint32_t min_depth, uint32_t max_depth) {
     const uint32_t n_lights = sc.n_lights;
@@ -459,7 +470,7 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
         v.m = load_mat(sc.mat, vin.obj);
         v.ls_emission = load_mat(sc.mat, vin.light_obj).color;
     }
-    if (DIFFUSE) __builtin_assume(v.m.tag <= MAT_EMISSIVE);
+    assume_mats<DIFFUSE>(v.m.tag);
     if (vin.hit_emitter) {
         if (!MIS || p.depth == 0u) {
             p.L = p.L + p.beta * v.m.color;                                       // rendering.rs:44-45 / :225-227
@@ -907,6 +918,284 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE ? kRegenWavesDiffuse : kRegenW
     }
 }
 
+// ------------------------------------------------------------------ the regenerating form for scenes with a few Mirror (GGX) objects
+// The reference's own scene (World::new(), world.rs:80-211) is 12 Lambertian / emissive triangles and ONE rough-glass
+// sphere.  In k_paths_regen paths of every depth share a wave, so nearly every iteration has a lane or two on the glass
+// and the whole GGX code (bsdf_pdf + VNDF sample + the lobe's Philox block, ~350-500 instructions) runs at a few percent
+// lane utilisation: C1 costs 37.5 us per million vertices against 26.3 for the same geometry with a Lambertian sphere
+// (tools/r03/c1_ggx_cost.py).  This form separates the two populations IN TIME inside each wave:
+//   * plain iterations are k_paths_regen's, compiled without the Mirror code (kMatsNoMirror).  A lane whose path ray
+//     turns out to hit a Mirror object (known after the closest-hit scan) does not shade it: it pushes the path -- the
+//     state BEFORE the vertex plus the scan's (id, t) -- onto the wave's SPECIAL stack and takes a new path like a lane
+//     whose path has ended.
+//   * when 64 Mirror vertices have piled up (or nothing else is left to do) the wave parks its 64 plain paths in memory,
+//     pops 64 special entries and runs ONE vertex for them with every lane on the GGX code (vertex_begin / scan / vertex_end
+//     of kMatsAll), then the closest-hit scan of their NEXT vertex: Mirror again (a path inside the sphere) -> back onto
+//     the special stack with its (id, t); anything else -> onto the wave's PLAIN stack, from which the regeneration step
+//     of the plain iterations takes entries before it takes camera rays.  Then the plain paths come back into the lanes.
+// Both stacks share one 128-entry region per wave in global memory (L2-resident: 18 KB per wave incl. the parking and
+// staging slots), special growing up, plain growing down.  They cannot collide: paths enter a wave only through camera-ray
+// regeneration, which happens only when the plain stack is empty and (batches run whenever >= 64 specials wait) at most
+// 63 specials wait, so lanes + stacks never hold more than 127 paths.  No atomics, no other wave involved.
+// Same per-vertex functions on the same inputs as every other form (a path's arithmetic does not depend on which lane
+// or in which order it is traced), so the film is bit-identical (test_level0_forms_give_the_same_film, the fuzz tests).
+constexpr int kWaitVm0 = 0x0F70;                                 // s_waitcnt vmcnt(0) alone (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+constexpr uint32_t kXq = 128;                                    // exchange entries per wave
+constexpr uint32_t kXqEntryF4 = 5;                               // stack entry: 4 float4 of path state (layout of Queue) + (bits(id), t, -, -)
+constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4 + 2u * 64u * 4u;   // the stacks + 64 parking + 64 staging slots of 4 float4
+static_assert(kXqF4PerWave == kRegenSplitF4PerWave, "pt_kernels.h sizes the buffer");
+// One wave-uniform base pointer (two scalar registers); entry-major, so the planes of an entry are immediate offsets of
+// ONE address -- with plane-major arrays the compiler kept a scalar base per plane (24 SGPRs more than the kernel has).
+struct XWave {
+    float4* b;
+    PT_DEV float4* entry(uint32_t e) const { return b + e * kXqEntryF4; }                  // [0..3] state, [4] = (bits(id), t, -, -) of a special entry's pending vertex
+    PT_DEV float4* park(uint32_t l) const { return b + kXq * kXqEntryF4 + l * 4u; }        // the wave's 64 plain paths while a batch of specials runs
+    PT_DEV float4* stage(uint32_t l) const { return b + kXq * kXqEntryF4 + 256u + l * 4u; }   // a batch's survivors while the scan of their next vertex decides their stack
+};
+PT_DEV XWave xwave(float4* base, uint32_t wave_uniform) {
+    XWave x;
+    x.b = base + (size_t)wave_uniform * kXqF4PerWave;
+    return x;
+}
+PT_DEV void store_entry(float4* e, const PathState& p) {
+    e[0] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+    e[1] = make_float4(p.d.y, p.d.z, __uint_as_float((p.yl << 16) | p.px), __uint_as_float((p.s_local << 16) | p.depth));
+    e[2] = make_float4(p.beta.x, p.beta.y, p.beta.z, p.pdf_prev);
+    e[3] = make_float4(p.L.x, p.L.y, p.L.z, p.eta_in);
+}
+PT_DEV bool is_mirror_obj(const SceneRef& sc, int id) { return (__float_as_uint(sc.mat[2 * id].x) & 0xFFu) == MAT_MIRROR; }
+
+// PLAIN = the material set of the plain iterations: kMatsDiffuse when the scene has no OrenNayar surface either (the
+// reference scene: exactly k_paths_regen<MIS, DIFFUSE>'s code there), else kMatsNoMirror.
+template <bool MIS, int PLAIN>
+__global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(BounceArgs a) {
+    extern __shared__ float4 lds[];
+    __shared__ float4 s_pool_d[kBlock / 64][kPool];
+    __shared__ uint32_t s_pool_s[kBlock / 64][kPool];
+    const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wib = threadIdx.x >> 6;
+    float4* const pool_d = s_pool_d[wib];
+    uint32_t* const pool_s = s_pool_s[wib];
+    const uint32_t n_first = a.n_first;
+    const uint32_t n_chunks = (n_first + 63u) >> 6;
+    const uint32_t W = a.film_w;
+    const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
+
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + wib, nw = gridDim.x * (kBlock / 64);
+    const XWave x = xwave(a.xchg, __builtin_amdgcn_readfirstlane(wave));
+    uint32_t st_next = wave;
+    uint32_t ctr = blockIdx.x % kRegenCounters, ctr_dry = 0;
+    uint32_t pool_head = 0, pool_cnt = 0;
+    bool exhausted = false;
+    uint32_t sq_cnt = 0, pq_cnt = 0;       // wave-uniform: special entries [0, sq_cnt), plain entries [kXq - pq_cnt, kXq)
+    uint32_t wave_shadow = 0, wave_vertices = 0;
+    uint32_t dmax = 0;
+    PathState p = parked_state();
+    bool alive = false;
+
+    for (;;) {
+        // ---- keep at least one chunk of camera rays in the ring (as k_paths_regen)
+        while (!exhausted && pool_cnt < 64u) {
+            uint32_t chunk;
+            if (st_next < a.regen_static) {
+                chunk = st_next; st_next += nw;
+            } else {
+                for (;;) {
+                    uint32_t got = 0;
+                    if (lane == 0u) got = atomicAdd(a.chunk_counter + ctr * kRegenCounterStride, 1u);
+                    chunk = a.regen_static + __builtin_amdgcn_readfirstlane(got) * kRegenCounters + ctr;
+                    if (chunk < n_chunks) break;
+                    ctr = ctr + 1u == kRegenCounters ? 0u : ctr + 1u;
+                    if (++ctr_dry == kRegenCounters) { exhausted = true; break; }
+                }
+                if (exhausted) break;
+            }
+            const uint32_t pid = chunk * 64u + lane;
+            const uint32_t valid = n_first - chunk * 64u < 64u ? n_first - chunk * 64u : 64u;
+            if (lane < valid) {
+                uint32_t s_local, pix, yl, px;
+                divmod_magic(pid, a.np, a.np_magic, s_local, pix);
+                divmod_magic(pix, W, a.film_w_magic, yl, px);
+                f3 o, d;
+                camera_ray(a.cam, a.s_base + s_local, px, image_row(a.tile, yl), o, d);
+                const uint32_t e = (pool_head + pool_cnt + lane) & (kPool - 1u);
+                pool_d[e] = make_float4(d.x, d.y, d.z, __uint_as_float((yl << 16) | px));
+                pool_s[e] = s_local << 16;
+            }
+            pool_cnt += valid;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lanes without a path: first the plain stack (paths that left a Mirror surface), then the ring
+        {
+            const unsigned long long need = __ballot(!alive);
+            const uint32_t r = lane_rank(need);
+            const uint32_t n_need = (uint32_t)__popcll(need);
+            const uint32_t n_pq = n_need < pq_cnt ? n_need : pq_cnt;
+            if (!alive && r < n_pq) {
+                const uint32_t e = kXq - pq_cnt + r;
+                const float4* src = x.entry(e);
+                p = unpack_state(src[0], src[1], src[2], src[3]);
+                // all four loads back HERE: otherwise the compiler waits (vmcnt(0)) at the first use of beta / L in the
+                // iteration below, on every path -- and on gfx9 that counter also holds the previous iteration's
+                // sample stores, a full HBM write latency per iteration (measured on C2, which never takes this
+                // branch: 7.5 instead of 6.2 ms)
+                __builtin_amdgcn_s_waitcnt(kWaitVm0);
+                alive = true;
+            } else if (!alive && r - n_pq < pool_cnt) {
+                const uint32_t e = (pool_head + r - n_pq) & (kPool - 1u);
+                const float4 q = pool_d[e];
+                const uint32_t sd = pool_s[e];
+                p.o = cam_o; p.d = mk(q.x, q.y, q.z);
+                const uint32_t xy = __float_as_uint(q.w);
+                p.yl = xy >> 16; p.px = xy & 0xFFFFu;
+                p.s_local = sd >> 16; p.depth = 0u;
+                p.beta = mk(1.f, 1.f, 1.f); p.L = mk(0.f, 0.f, 0.f);
+                p.pdf_prev = 0.0f; p.eta_in = 1.0f;
+                alive = true;
+            }
+            pq_cnt -= n_pq;
+            const uint32_t n_ring = n_need - n_pq < pool_cnt ? n_need - n_pq : pool_cnt;
+            pool_head += n_ring; pool_cnt -= n_ring;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+        // no plain path although stack and ring were offered: the batch is used up.  Without waiting specials the wave is done.
+        if (n_alive == 0u && sq_cnt == 0u) break;
+
+        if (n_alive != 0u) {
+            // ---- plain iteration: scan #1 (rendering.rs:41)
+            int id; float t;
+            scan_closest<kModeLds>(sc, p.o, p.d, a.t_min, kInf, id, t);
+            // a Mirror vertex is not shaded here: the path waits on the special stack for a batch of its kind
+            const bool special = alive && id >= 0 && is_mirror_obj(sc, id);
+            const unsigned long long spm = __ballot(special);
+            if (spm != 0ull) {
+                if (special) {
+                    float4* dst = x.entry(sq_cnt + lane_rank(spm));
+                    store_entry(dst, p);
+                    dst[4] = make_float4(__int_as_float(id), t, 0.0f, 0.0f);
+                    alive = false;
+                    p.o = parked_origin(); p.d = parked_dir();
+                    id = -1;
+                }
+                sq_cnt += (uint32_t)__popcll(spm);
+            }
+            const bool active = alive;
+            const uint32_t kx = p.px, py = image_row(a.tile, p.yl);
+            const uint32_t sample = a.s_base + p.s_local;
+            wave_vertices += (uint32_t)__popcll(__ballot(active));
+            Vertex v;
+            vertex_begin<MIS, PLAIN>(sc, p, active, id, t, sample, kx, py, v);
+            bool visible = false;
+            if (MIS) {
+                const unsigned long long sm = __ballot(v.need_shadow);
+                if (sm != 0ull) {
+                    f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
+                    f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
+                    int sid; float st;
+                    scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                    visible = v.need_shadow && sid < 0;
+                    wave_shadow += (uint32_t)__popcll(sm);
+                }
+            }
+            alive = vertex_end<MIS, PLAIN, true>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
+            if (active && !alive) {
+                a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
+                dmax = p.depth > dmax ? p.depth : dmax;
+                p.o = parked_origin(); p.d = parked_dir();
+            }
+        }
+
+        // ---- batches of Mirror vertices: whenever a full wave of them waits, or nothing else is left to do
+        auto plain_work = [&]() { return __ballot(alive) != 0ull || pool_cnt != 0u || !exhausted || pq_cnt != 0u; };
+        if (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work())) {
+            // park the plain paths: their 16 registers are free during the batch.  (The lane index goes through an empty
+            // asm so that the compiler computes the parking / staging addresses here instead of hoisting twelve 64-bit
+            // address pairs out of the path loop into registers it then has to spill.)
+            uint32_t ln = lane;
+            asm volatile("" : "+v"(ln));
+            store_entry(x.park(ln), p);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // entries pushed above are read by other lanes below
+            do {
+                const uint32_t n = sq_cnt < 64u ? sq_cnt : 64u;
+                const bool qa = lane < n;
+                const uint32_t e = sq_cnt - n + (qa ? lane : 0u);     // the top n entries
+                PathState q = parked_state();
+                int qid = -1; float qt = 0.0f;
+                if (qa) {
+                    const float4* src = x.entry(e);
+                    unpack_ray(q, src[0], src[1]);
+                    const float4 it = src[4];
+                    qid = __float_as_int(it.x); qt = it.y;
+                }
+                sq_cnt -= n;
+                const uint32_t kx = q.px, py = image_row(a.tile, q.yl);
+                const uint32_t sample = a.s_base + q.s_local;
+                wave_vertices += n;
+                Vertex v;
+                vertex_begin<MIS, kMatsAll>(sc, q, qa, qid, qt, sample, kx, py, v);
+                bool visible = false;
+                if (MIS) {
+                    const unsigned long long sm = __ballot(v.need_shadow);
+                    if (sm != 0ull) {
+                        f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
+                        f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
+                        int sid; float st;
+                        scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                        visible = v.need_shadow && sid < 0;
+                        wave_shadow += (uint32_t)__popcll(sm);
+                    }
+                }
+                // the carry part only now (as k_paths does): eight registers less during the scans
+                asm volatile("" ::: "memory");
+                if (qa) { const float4* src = x.entry(e); unpack_carry(q, src[2], src[3]); }
+                const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
+                if (qa && !qalive) {
+                    a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
+                    dmax = q.depth > dmax ? q.depth : dmax;
+                }
+                // the survivors' next vertex: Mirror again (a path inside the sphere) or not?  Their state waits in the
+                // staging slots meanwhile; the scan needs the ray only.
+                uint32_t ls = lane;
+                asm volatile("" : "+v"(ls));
+                if (qalive) store_entry(x.stage(ls), q);
+                const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
+                asm volatile("" ::: "memory");
+                int id2; float t2;
+                scan_closest<kModeLds>(sc, so, sd, a.t_min, kInf, id2, t2);
+                const bool spec2 = qalive && id2 >= 0 && is_mirror_obj(sc, id2);
+                const bool plain2 = qalive && !spec2;
+                const unsigned long long m_s = __ballot(spec2), m_p = __ballot(plain2);
+                const uint32_t n_p = (uint32_t)__popcll(m_p);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                if (qalive) {
+                    const uint32_t dst = spec2 ? sq_cnt + lane_rank(m_s) : kXq - pq_cnt - n_p + lane_rank(m_p);
+                    const float4* sg = x.stage(ls);
+                    const float4 s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3];
+                    float4* de = x.entry(dst);
+                    de[0] = s0; de[1] = s1; de[2] = s2; de[3] = s3;
+                    if (spec2) de[4] = make_float4(__int_as_float(id2), t2, 0.0f, 0.0f);
+                }
+                sq_cnt += (uint32_t)__popcll(m_s);
+                pq_cnt += n_p;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            } while (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work()));
+            asm volatile("" : "+v"(ln));
+            { const float4* pk = x.park(ln); p = unpack_state(pk[0], pk[1], pk[2], pk[3]); }
+            __builtin_amdgcn_s_waitcnt(kWaitVm0);      // as above: no pending load may leave this branch
+        }
+    }
+
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off); dmax = w2 > dmax ? w2 : dmax; }
+    if (lane == 0u) {
+        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
+        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
+        if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
+        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
+    }
+}
+
 // ------------------------------------------------------------------ the path kernel, BVH form
 // Same organisation as k_paths (one launch per batch, wave-private queue segments compacted in place, tail
 // hand-off), but a BVH traversal diverges: rays of one wave need between a handful and a few hundred steps,
@@ -1228,6 +1517,11 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
     if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen)
         const bool mis = a.integrator == 0;
         const dim3 g(grid), b(kBlock);
+        if (a.xchg) {                              // ... with the Mirror vertices batched (k_paths_regen_split)
+            if (a.sc.no_oren_nayar) { if (mis) hipLaunchKernelGGL((k_paths_regen_split<true, kMatsDiffuse>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen_split<false, kMatsDiffuse>), g, b, lds, st, a); }
+            else { if (mis) hipLaunchKernelGGL((k_paths_regen_split<true, kMatsNoMirror>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen_split<false, kMatsNoMirror>), g, b, lds, st, a); }
+            return;
+        }
         if (diffuse) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, true>), g, b, lds, st, a); }
         else { if (mis) hipLaunchKernelGGL((k_paths_regen<true, false>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, false>), g, b, lds, st, a); }
         return;

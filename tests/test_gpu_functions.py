@@ -269,8 +269,10 @@ def test_ray_color_on_arbitrary_rays(pt, orc, gpu_ctx, integrator):
 
 
 # ---------------------------------------------------------------- the entry is asynchronous / graph-capturable
-@pytest.mark.parametrize("scene", [1, 2])     # 1: queue-form level-0 launch (GGX surface), 2: regenerating form (chunk counters reset by a memset node)
-def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene):
+# (1, 1): queue-form level-0 launch + continuation launch; (1, 0): the reference scene's default, the regenerating form with
+# batched Mirror vertices; (2, 0): regenerating form (chunk counters reset by a memset node)
+@pytest.mark.parametrize("scene,form", [(1, 1), (1, 0), (2, 0)])
+def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene, form):
     """pt_render_device enqueues and returns: no host synchronisation, no allocation once its buffers exist.  So it can
     be captured into a hipGraph (torch.cuda.CUDAGraph on the stream the context renders on) and replayed; the film of
     a replay is the film of a direct call.  1024 x 1024 x 8 spp = 8.4 M paths: large enough for the tail hand-off
@@ -278,11 +280,12 @@ def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene):
     import torch
     objs = pt.builtin_scene(scene)
     gpu_ctx.upload(objs)
+    gpu_ctx.set_tuning(level0_form=form)
     cam = pt.camera_new(width=1024, height=1024)
     prm = pt.default_params(spp=8)
     ref, ref8 = gpu_ctx.render(cam, prm)                       # also creates every buffer of this size
     st = gpu_ctx.stats()
-    assert st.bounce_launches == (2 if scene == 1 else 1) and st.batches == 1     # regenerating waves run dry themselves
+    assert st.bounce_launches == (2 if form == 1 else 1) and st.batches == 1     # regenerating waves run dry themselves
     dev = torch.device("cuda", 0)
     lin = torch.zeros_like(ref); rgba = torch.zeros_like(ref8)
     stream = torch.cuda.Stream(dev)
@@ -297,6 +300,7 @@ def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene):
             stream.synchronize()
             assert torch.equal(lin, ref) and torch.equal(rgba, ref8)
     gpu_ctx.set_stream(None)
+    gpu_ctx.set_tuning()
     del g
 
 
@@ -334,7 +338,9 @@ def test_level0_forms_give_the_same_film(pt, gpu_ctx, scene, exact):
         ref, ref8 = gpu_ctx.render(cam, prm)
         base = gpu_ctx.stats()
         assert base.bounce_launches == 2
-        for form, wgs, eb in [(2, 0, 0), (2, 1, 0), (2, 333, 3), (2, 4000, 64), (0, 0, 0)]:
+        # 3 = the regenerating form that sets Mirror vertices aside and shades them in batches (k_paths_regen_split; the
+        # default for the reference scene; for the diffuse scene the request falls back to the queue form)
+        for form, wgs, eb in [(2, 0, 0), (2, 1, 0), (2, 333, 3), (2, 4000, 64), (3, 0, 0), (3, 1, 0), (3, 333, 0), (3, 4000, 0), (0, 0, 0)]:
             gpu_ctx.set_tuning(level0_form=form, regen_workgroups=wgs, export_below=eb)
             lin, rgba = gpu_ctx.render(cam, prm)
             st = gpu_ctx.stats()

@@ -113,9 +113,15 @@ def test_random_scene_regenerating_form_equals_queue_form(pt, gpu_ctx, seed):
         # the forms really were the two: level-0 + continuation launch; one regenerating launch whose waves run dry
         # (with a hand-over threshold: + the continuation launch)
         assert base.bounce_launches == 2 and st.bounce_launches == (1 if eb == 0 else 2)
+        # the form that batches the Mirror vertices of a wave (k_paths_regen_split), whatever share of the scene is Mirror
+        gpu_ctx.set_tuning(level0_form=3, regen_workgroups=int(rng.choice([0, 0, 97, 3000])))
+        lin3, rgba3 = gpu_ctx.render(cam, prm)
+        st3 = gpu_ctx.stats()
     finally:
         gpu_ctx.set_tuning()
     a, b = lin.cpu().numpy(), ref.cpu().numpy()
     assert np.array_equal(a, b, equal_nan=True), f"seed {seed}: {(a != b).any(-1).sum()} pixels differ"
     assert torch.equal(rgba, ref8)
     assert (st.vertices, st.shadow_rays, st.max_depth_reached) == (base.vertices, base.shadow_rays, base.max_depth_reached)
+    assert np.array_equal(lin3.cpu().numpy(), b, equal_nan=True) and torch.equal(rgba3, ref8), f"seed {seed}: split form"
+    assert (st3.vertices, st3.shadow_rays, st3.max_depth_reached) == (base.vertices, base.shadow_rays, base.max_depth_reached)
