@@ -241,9 +241,9 @@ int ensure_bvh(PtContext* c) {
         return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate; the linear scan's answer for them "
                                         "depends on the scan order, use the linear scan", b.non_finite);
     }
-    if (b.depth + 2u > ptbvh::kStackDepth) {
+    if (b.depth + 2u > ptbvh::kStackDepth || b.stack_need > ptbvh::kStackDepth) {
         c->bvh_failed = true;        // a property of the scene: do not rebuild on every render
-        return fail(PT_ERR_UNSUPPORTED, "accel: BVH depth %u exceeds the traversal stack", b.depth);
+        return fail(PT_ERR_UNSUPPORTED, "accel: BVH (depth %u, stack need %u) exceeds the traversal stack", b.depth, b.stack_need);
     }
     int rc;
     if ((rc = c->bvh_nodes.ensure(b.qnodes.size() + 2)) || (rc = c->bvh_rec.ensure(b.leaf_rec.size() + 3)) ||
@@ -921,10 +921,11 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
     }
     const ptbvh::Built b = ptbvh::build(shape.data(), tag.data(), n);
     if (depth) *depth = b.depth;
-    if (n_nodes) *n_nodes = (uint32_t)(b.nodes.size() / 4);
+    if (n_nodes) *n_nodes = (uint32_t)b.wide.size();
     if (n_leaf_slots) *n_leaf_slots = b.leaf_prims;          // slots that hold a primitive (leaves are padded to multiples of 4 slots)
     if (b.non_finite) return fail(PT_ERR_UNSUPPORTED, "accel: %u object(s) with a NaN/inf coordinate", b.non_finite);
-    if (b.depth + 2u > ptbvh::kStackDepth) return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", b.depth);
+    if (b.depth + 2u > ptbvh::kStackDepth || b.stack_need > ptbvh::kStackDepth)
+        return fail(PT_ERR_UNSUPPORTED, "BVH (depth %u, stack need %u) exceeds the traversal stack", b.depth, b.stack_need);
     if (b.leaf_prims != n || b.leaf_rec.size() != 3 * b.leaf_ids.size() || b.leaf_lead.size() != b.leaf_ids.size() || b.leaf_ids.size() % 4u != 0u)
         return fail(PT_ERR_UNSUPPORTED, "%u primitives in %zu leaf slots for %u objects", b.leaf_prims, b.leaf_ids.size(), n);
     if (n == 0) return b.root == ptbvh::kDone ? PT_OK : fail(PT_ERR_UNSUPPORTED, "empty scene: root is not the sentinel");
@@ -945,13 +946,14 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
     };
     std::vector<uint8_t> seen(n, 0);
     std::string err;
-    // returns the exact bounds of the subtree; checks them against the box the parent stores for it
+    // returns the exact bounds of the subtree and the stack entries a traversal can need below it (sum over the deepest
+    // path of children - 1); checks the bounds against the box the parent stores for the subtree
     struct Walker {
         const ptbvh::Built& b; const std::vector<float4>& scan; const std::vector<uint32_t>& tag; std::vector<uint8_t>& seen;
-        decltype(prim_box)& pbox; std::string& err; uint32_t n; uint32_t max_depth = 0;
-        bool walk(uint32_t code, uint32_t d, double lo[3], double hi[3]) {
+        decltype(prim_box)& pbox; std::string& err; uint32_t n;
+        bool walk(uint32_t code, double lo[3], double hi[3], uint32_t* need) {
             for (int k = 0; k < 3; ++k) { lo[k] = 1e300; hi[k] = -1e300; }
-            if (d > max_depth) max_depth = d;
+            *need = 0;
             if (code == ptbvh::kDone) { err = "sentinel inside the tree"; return false; }
             if (code & ptbvh::kLeafBit) {
                 const uint32_t first = code & 0x0FFFFFFFu, cnt = ((code >> 28) & 7u) + 1u;
@@ -970,41 +972,47 @@ int pt_debug_bvh_check(const PtObject* objs, uint32_t n, uint32_t* depth, uint32
                 }
                 return true;
             }
-            if (4 * (size_t)code + 3 >= b.nodes.size()) { err = "node index out of bounds"; return false; }
-            const float4 n0 = b.nodes[4 * (size_t)code], n1 = b.nodes[4 * (size_t)code + 1], n2 = b.nodes[4 * (size_t)code + 2],
-                         n3 = b.nodes[4 * (size_t)code + 3];
-            const float flo[2][3] = {{n0.x, n0.y, n0.z}, {n1.z, n1.w, n2.x}}, fhi[2][3] = {{n0.w, n1.x, n1.y}, {n2.y, n2.z, n2.w}};
-            uint32_t cc[2];
-            std::memcpy(&cc[0], &n3.x, 4); std::memcpy(&cc[1], &n3.y, 4);
+            if ((size_t)code >= b.wide.size()) { err = "node index out of bounds"; return false; }
+            const ptbvh::WideNode& wn = b.wide[code];
+            if (wn.n < 2 || wn.n > ptbvh::kWidth) { err = "node with fewer than 2 or more than 4 children"; return false; }
             // what the device traverses: the boxes decoded from the 16-bit grid; they must contain the f32 boxes
-            if (2 * (size_t)code + 1 >= b.qnodes.size()) { err = "quantised node index out of bounds"; return false; }
-            const uint4 qa = b.qnodes[2 * (size_t)code], qb = b.qnodes[2 * (size_t)code + 1];
-            if (qb.z != cc[0] || qb.w != cc[1]) { err = "quantised node carries other child codes"; return false; }
-            const uint32_t qw[2][3] = {{qa.x, qa.y, qa.z}, {qa.w, qb.x, qb.y}};
-            float blo[2][3], bhi[2][3];
-            for (int c = 0; c < 2; ++c) {
-                const uint32_t q[6] = {qw[c][0] & 0xFFFFu, qw[c][0] >> 16, qw[c][1] & 0xFFFFu, qw[c][1] >> 16, qw[c][2] & 0xFFFFu, qw[c][2] >> 16};
-                for (int k = 0; k < 3; ++k) {
-                    blo[c][k] = std::fmaf((float)q[k], b.grid_cell[k], b.grid_min[k]);
-                    bhi[c][k] = std::fmaf((float)q[3 + k], b.grid_cell[k], b.grid_min[k]);
-                    if (!(blo[c][k] <= flo[c][k] && bhi[c][k] >= fhi[c][k])) { err = "quantised child box does not contain the f32 box"; return false; }
+            if (4 * (size_t)code + 3 >= b.qnodes.size()) { err = "quantised node index out of bounds"; return false; }
+            const uint4 qa = b.qnodes[4 * (size_t)code], qb = b.qnodes[4 * (size_t)code + 1], qc = b.qnodes[4 * (size_t)code + 2],
+                        qd = b.qnodes[4 * (size_t)code + 3];
+            const uint32_t qcode[4] = {qd.x, qd.y, qd.z, qd.w};
+            const uint32_t qw[4][3] = {{qa.x, qa.y, qa.z}, {qa.w, qb.x, qb.y}, {qb.z, qb.w, qc.x}, {qc.y, qc.z, qc.w}};
+            uint32_t need_below = 0;
+            for (uint32_t c = 0; c < ptbvh::kWidth; ++c) {
+                if (qcode[c] != wn.code[c]) { err = "quantised node carries other child codes"; return false; }
+                if (c >= wn.n) {
+                    if (wn.code[c] != ptbvh::kDone) { err = "unused child slot without the sentinel code"; return false; }
+                    continue;
                 }
-            }
-            for (int c = 0; c < 2; ++c) {
-                double cl[3], ch[3];
-                if (!walk(cc[c], d + 1, cl, ch)) return false;
+                const uint32_t q[6] = {qw[c][0] & 0xFFFFu, qw[c][0] >> 16, qw[c][1] & 0xFFFFu, qw[c][1] >> 16, qw[c][2] & 0xFFFFu, qw[c][2] >> 16};
+                float blo[3], bhi[3];
                 for (int k = 0; k < 3; ++k) {
-                    if (!((double)blo[c][k] <= cl[k] && (double)bhi[c][k] >= ch[k])) { err = "child box does not enclose its subtree"; return false; }
+                    blo[k] = std::fmaf((float)q[k], b.grid_cell[k], b.grid_min[k]);
+                    bhi[k] = std::fmaf((float)q[3 + k], b.grid_cell[k], b.grid_min[k]);
+                    if (!(blo[k] <= wn.lo[c][k] && bhi[k] >= wn.hi[c][k])) { err = "quantised child box does not contain the f32 box"; return false; }
+                }
+                double cl[3], ch[3];
+                uint32_t nd = 0;
+                if (!walk(wn.code[c], cl, ch, &nd)) return false;
+                need_below = std::max(need_below, nd);
+                for (int k = 0; k < 3; ++k) {
+                    if (!((double)blo[k] <= cl[k] && (double)bhi[k] >= ch[k])) { err = "child box does not enclose its subtree"; return false; }
                     lo[k] = std::min(lo[k], cl[k]); hi[k] = std::max(hi[k], ch[k]);
                 }
             }
+            *need = (wn.n - 1u) + need_below;
             return true;
         }
     } w{b, scan, tag, seen, prim_box, err, n};
+    uint32_t need = 0;
     double lo[3], hi[3];
-    if (!w.walk(b.root, 0, lo, hi)) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: %s", err.c_str());
+    if (!w.walk(b.root, lo, hi, &need)) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: %s", err.c_str());
     for (uint32_t i = 0; i < n; ++i) if (!seen[i]) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: object %u is in no leaf", i);
-    if (w.max_depth != b.depth) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: depth %u reported, %u found", b.depth, w.max_depth);
+    if (1u + need != b.stack_need) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: stack need %u reported, %u found", b.stack_need, 1u + need);
     double amax = 0.0;
     for (int k = 0; k < 3; ++k) amax += std::max(std::fabs(lo[k]), std::fabs(hi[k]));
     if (!((double)b.scene_abs >= amax)) return fail(PT_ERR_UNSUPPORTED, "BVH invariant: scene_abs %g below the scene extent %g", (double)b.scene_abs, amax);

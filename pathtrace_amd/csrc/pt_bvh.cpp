@@ -1,5 +1,6 @@
-// pt_bvh.cpp -- host-side BVH builder (see pt_bvh.h).  Binned SAH near the root, object-median
-// splits wherever SAH could make the tree deeper than the traversal stack.
+// pt_bvh.cpp -- host-side BVH builder (see pt_bvh.h).  A binary tree first -- binned SAH near the root, object-median
+// splits wherever SAH could make the tree deeper than the traversal stack --, then collapsed into nodes of up to four
+// children wherever the stack budget allows.
 #include "pt_bvh.h"
 
 #include <algorithm>
@@ -40,8 +41,16 @@ uint32_t median_levels(uint64_t m) {
 constexpr uint32_t kMaxDepth = kStackDepth - 2;   // deepest leaf the traversal stack (sentinel + one push per level) can take
 constexpr int kBins = 16;
 
+// node of the binary tree (temporary): child = leaf code, or index into Builder::bin
+struct BinNode {
+    Box box[2];
+    uint32_t child[2];
+    uint32_t height;          // levels of internal nodes below and including this one on its deepest path (a node of two leaves: 1)
+};
+
 struct Builder {
     std::vector<Prim> prims;
+    std::vector<BinNode> bin;
     const float4* shape;
     const uint32_t* tag;
     Built out;
@@ -126,38 +135,83 @@ struct Builder {
             std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
                              [ax](const Prim& a, const Prim& b) { return a.cen[ax] < b.cen[ax] || (a.cen[ax] == b.cen[ax] && a.obj < b.obj); });
         }
-        const uint32_t node = (uint32_t)(out.nodes.size() / 4);
-        out.nodes.resize(out.nodes.size() + 4);
+        const uint32_t node = (uint32_t)bin.size();
+        bin.emplace_back();
         Box b0, b1;
         const uint32_t c0 = build(first, mid - first, depth + 1, &b0);
         const uint32_t c1 = build(mid, first + count - mid, depth + 1, &b1);
-        float cb0, cb1;
-        std::memcpy(&cb0, &c0, 4); std::memcpy(&cb1, &c1, 4);
-        out.nodes[4 * (size_t)node + 0] = make_float4(b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]);
-        out.nodes[4 * (size_t)node + 1] = make_float4(b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]);
-        out.nodes[4 * (size_t)node + 2] = make_float4(b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]);
-        out.nodes[4 * (size_t)node + 3] = make_float4(cb0, cb1, 0.f, 0.f);
+        BinNode& bn = bin[node];
+        bn.box[0] = b0; bn.box[1] = b1;
+        bn.child[0] = c0; bn.child[1] = c1;
+        bn.height = 1u + std::max(height_of(c0), height_of(c1));
         return node;
+    }
+    uint32_t height_of(uint32_t code) const { return (code & kLeafBit) ? 0u : bin[code].height; }
+
+    // Binary subtree `b` -> wide node; returns its index.  budget = stack entries the traversal may use below this
+    // node's parent (need of the subtree <= budget).  A binary subtree of height h needs h entries as it is (one push per
+    // level); pulling a grandchild pair up into the node costs one more entry for EVERY path through the node, so it is
+    // done (largest box first) only while every child's binary height still fits what is left.
+    uint32_t collapse(uint32_t b, uint32_t budget, uint32_t* need_out) {
+        struct Item { Box box; uint32_t code; };
+        Item it[kWidth];
+        uint32_t c = 2;
+        it[0] = {bin[b].box[0], bin[b].child[0]};
+        it[1] = {bin[b].box[1], bin[b].child[1]};
+        while (c < kWidth) {
+            int best = -1;
+            double best_area = -1.0;
+            for (uint32_t k = 0; k < c; ++k) {
+                if (it[k].code & kLeafBit) continue;
+                // after opening child k the node has c + 1 children: every child subtree must fit budget - c
+                bool ok = true;
+                for (uint32_t j = 0; j < c && ok; ++j)
+                    if (j != k) ok = height_of(it[j].code) + c <= budget;
+                const BinNode& g = bin[it[k].code];
+                ok = ok && height_of(g.child[0]) + c <= budget && height_of(g.child[1]) + c <= budget;
+                if (!ok) continue;
+                const double a = it[k].box.half_area();
+                if (a > best_area) { best_area = a; best = (int)k; }
+            }
+            if (best < 0) break;
+            const BinNode& g = bin[it[best].code];
+            it[best] = {g.box[0], g.child[0]};
+            it[c++] = {g.box[1], g.child[1]};
+        }
+        const uint32_t w = (uint32_t)out.wide.size();
+        out.wide.emplace_back();
+        uint32_t need_below = 0;
+        for (uint32_t k = 0; k < kWidth; ++k) {
+            uint32_t code = kDone;
+            Box bx; bx.reset();
+            if (k < c) {
+                bx = it[k].box;
+                code = it[k].code;
+                if (!(code & kLeafBit)) {
+                    uint32_t nd = 0;
+                    code = collapse(code, budget - (c - 1u), &nd);
+                    need_below = std::max(need_below, nd);
+                }
+            }
+            WideNode& wn = out.wide[w];
+            for (int a = 0; a < 3; ++a) { wn.lo[k][a] = bx.lo[a]; wn.hi[k][a] = bx.hi[a]; }
+            wn.code[k] = code;
+        }
+        out.wide[w].n = c;
+        *need_out = (c - 1u) + need_below;
+        return w;
     }
 };
 
 // Child boxes -> 16-bit grid coordinates over the bounds of all child boxes (see pt_bvh.h).
 void quantise(Built& t) {
-    const size_t n_nodes = t.nodes.size() / 4;
-    t.qnodes.assign(2 * n_nodes, make_uint4(0, 0, 0, 0));
+    const size_t n_nodes = t.wide.size();
+    t.qnodes.assign(4 * n_nodes, make_uint4(0, 0, 0, 0));
     if (n_nodes == 0) return;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    auto boxes = [&](size_t k, float blo[2][3], float bhi[2][3]) {
-        const float4 n0 = t.nodes[4 * k], n1 = t.nodes[4 * k + 1], n2 = t.nodes[4 * k + 2];
-        const float l[2][3] = {{n0.x, n0.y, n0.z}, {n1.z, n1.w, n2.x}}, h[2][3] = {{n0.w, n1.x, n1.y}, {n2.y, n2.z, n2.w}};
-        std::memcpy(blo, l, sizeof l); std::memcpy(bhi, h, sizeof h);
-    };
-    for (size_t k = 0; k < n_nodes; ++k) {
-        float blo[2][3], bhi[2][3];
-        boxes(k, blo, bhi);
-        for (int c = 0; c < 2; ++c)
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)blo[c][a]); hi[a] = std::max(hi[a], (double)bhi[c][a]); }
-    }
+    for (const WideNode& w : t.wide)
+        for (uint32_t c = 0; c < w.n; ++c)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)w.lo[c][a]); hi[a] = std::max(hi[a], (double)w.hi[c][a]); }
     for (int a = 0; a < 3; ++a) {
         t.grid_min[a] = down(lo[a]);
         const double ext = std::max(hi[a] - (double)t.grid_min[a], 1e-30);
@@ -177,18 +231,18 @@ void quantise(Built& t) {
         return (uint32_t)q;
     };
     for (size_t k = 0; k < n_nodes; ++k) {
-        float blo[2][3], bhi[2][3];
-        boxes(k, blo, bhi);
-        uint32_t w[2][3];
-        for (int c = 0; c < 2; ++c) {
-            const uint32_t lx = q_lo(0, blo[c][0]), ly = q_lo(1, blo[c][1]), lz = q_lo(2, blo[c][2]);
-            const uint32_t hx = q_hi(0, bhi[c][0]), hy = q_hi(1, bhi[c][1]), hz = q_hi(2, bhi[c][2]);
-            w[c][0] = lx | (ly << 16); w[c][1] = lz | (hx << 16); w[c][2] = hy | (hz << 16);
+        const WideNode& w = t.wide[k];
+        uint32_t v[kWidth][3];
+        for (uint32_t c = 0; c < kWidth; ++c) {
+            if (c >= w.n) { v[c][0] = v[c][1] = v[c][2] = 0u; continue; }      // unused slot: its code (kDone) keeps the traversal out
+            const uint32_t lx = q_lo(0, w.lo[c][0]), ly = q_lo(1, w.lo[c][1]), lz = q_lo(2, w.lo[c][2]);
+            const uint32_t hx = q_hi(0, w.hi[c][0]), hy = q_hi(1, w.hi[c][1]), hz = q_hi(2, w.hi[c][2]);
+            v[c][0] = lx | (ly << 16); v[c][1] = lz | (hx << 16); v[c][2] = hy | (hz << 16);
         }
-        uint32_t c0, c1;
-        std::memcpy(&c0, &t.nodes[4 * k + 3].x, 4); std::memcpy(&c1, &t.nodes[4 * k + 3].y, 4);
-        t.qnodes[2 * k] = make_uint4(w[0][0], w[0][1], w[0][2], w[1][0]);
-        t.qnodes[2 * k + 1] = make_uint4(w[1][1], w[1][2], c0, c1);
+        t.qnodes[4 * k] = make_uint4(v[0][0], v[0][1], v[0][2], v[1][0]);
+        t.qnodes[4 * k + 1] = make_uint4(v[1][1], v[1][2], v[2][0], v[2][1]);
+        t.qnodes[4 * k + 2] = make_uint4(v[2][2], v[3][0], v[3][1], v[3][2]);
+        t.qnodes[4 * k + 3] = make_uint4(w.code[0], w.code[1], w.code[2], w.code[3]);
     }
 }
 
@@ -231,12 +285,19 @@ Built build(const float4* shape, const uint32_t* shape_tag, uint32_t n) {
             }
         }
     }
-    b.out.nodes.reserve(4 * (size_t)n);
+    b.bin.reserve(n);
     b.out.leaf_ids.reserve(n);
     b.out.leaf_rec.reserve(3 * (size_t)n);
     if (n != 0) {
         Box root;
-        b.out.root = b.build(0, n, 0, &root);
+        uint32_t r = b.build(0, n, 0, &root);
+        if (!(r & kLeafBit)) {
+            // the binary tree is at most kMaxDepth deep: as it stands it fits the budget, and the collapse never breaks that
+            uint32_t need = 0;
+            r = b.collapse(r, kStackDepth - 2u, &need);
+            b.out.stack_need = 1u + need;
+        }
+        b.out.root = r;
     }
     b.out.scene_abs = up(amax[0] + amax[1] + amax[2]);
     while (b.out.leaf_ids.size() % 4u != 0u) {                   // the last leaf's 16-byte id load stays in bounds

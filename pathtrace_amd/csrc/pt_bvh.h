@@ -1,6 +1,6 @@
 // pt_bvh.h -- optional acceleration structure for World::hit_scene (the reference
-// itself is linear-scan only, world.rs:281).  A binary BVH over the objects' f32 bounding boxes,
-// built on the host at first use.  It only decides WHICH primitives a ray is tested against; the
+// itself is linear-scan only, world.rs:281).  A 4-wide BVH over the objects' f32 bounding boxes (a binned-SAH
+// binary tree, collapsed), built on the host at first use.  It only decides WHICH primitives a ray is tested against; the
 // primitive tests are the ones of the linear scan, and the winner is chosen by the rule the scan
 // implies (smallest t; among equal t the highest object index), so the answer does not depend on
 // the traversal order.
@@ -17,18 +17,26 @@ namespace ptbvh {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kDone = 0xFFFFFFFFu;      // stack sentinel / root of an empty scene (no leaf code: a leaf holds <= 4 primitives)
 constexpr uint32_t kMaxLeaf = 4;             // primitives per leaf
-constexpr uint32_t kStackDepth = 24;         // traversal stack entries per lane (LDS); the builder keeps the tree this shallow (<= 16 M objects)
+constexpr uint32_t kWidth = 4;               // children per internal node
+constexpr uint32_t kStackDepth = 24;         // traversal stack entries per lane (LDS); the builder keeps the tree's stack need within it (<= 16 M objects)
 constexpr uint32_t kTriangleBit = 0x80000000u;   // in leaf_ids: the primitive is a triangle
 
+// Internal node as the builder and the checker see it: up to kWidth children, each with the f32 box of its subtree.
+// Unused child slots carry the code kDone (the traversal never enters them).
+struct WideNode {
+    float lo[kWidth][3], hi[kWidth][3];
+    uint32_t code[kWidth];
+    uint32_t n;                       // children in use (2 .. kWidth), slots [0, n)
+};
+
 struct Built {
-    // internal node k = nodes[4k .. 4k+3]:
-    //   n0 = (lo0.x, lo0.y, lo0.z, hi0.x)  n1 = (hi0.y, hi0.z, lo1.x, lo1.y)  n2 = (lo1.z, hi1.x, hi1.y, hi1.z)
-    //   n3 = (bits child0, bits child1, 0, 0)
-    std::vector<float4> nodes;
-    // What the device traverses: the same nodes with the child boxes on a 16-bit grid over the scene's bounds,
-    // 32 bytes each (two 16-byte loads per visit instead of four -- the traversal is bound by L1 traffic).
-    //   qnodes[2k]   = (c0.w0, c0.w1, c0.w2, c1.w0)      w0 = lo.x | lo.y << 16, w1 = lo.z | hi.x << 16, w2 = hi.y | hi.z << 16
-    //   qnodes[2k+1] = (c1.w1, c1.w2, code child0, code child1)
+    std::vector<WideNode> wide;
+    // What the device traverses: the same nodes with the child boxes on a 16-bit grid over the scene's bounds, 64 bytes
+    // (one cache line, four 16-byte loads) per visit.  Round 2's binary nodes took two dependent 32-byte visits for what
+    // one visit decides here; the traversal is bound by the latency of those dependent fetches.
+    //   child c = three words  w0 = lo.x | lo.y << 16, w1 = lo.z | hi.x << 16, w2 = hi.y | hi.z << 16
+    //   qnodes[4k]   = (c0.w0, c0.w1, c0.w2, c1.w0)    qnodes[4k+1] = (c1.w1, c1.w2, c2.w0, c2.w1)
+    //   qnodes[4k+2] = (c2.w2, c3.w0, c3.w1, c3.w2)    qnodes[4k+3] = (code0, code1, code2, code3)
     // coordinate = grid_min[axis] + q * grid_cell[axis], evaluated as fmaf((float)q, cell, min); lower planes are
     // rounded down and upper planes up until that f32 expression encloses the f32 box, so a quantised box contains
     // the exact one (it only prunes less).
@@ -41,7 +49,11 @@ struct Built {
     std::vector<uint32_t> leaf_ids;   // object index of the leaf slot (| kTriangleBit)
     uint32_t leaf_prims = 0;          // slots that hold a primitive (= number of objects)
     uint32_t root = kDone;            // child code of the root
-    uint32_t depth = 0;               // deepest leaf (root = 0)
+    uint32_t depth = 0;               // deepest leaf of the BINARY tree the nodes were collapsed from (root = 0)
+    // Stack entries a traversal can need: 1 (sentinel) + the largest sum over a root-to-leaf path of (children - 1): a
+    // visit pushes every hit child but the one it descends into.  The collapse keeps it <= kStackDepth (it merges a
+    // binary node's grandchildren into the node only where the remaining budget still covers the subtrees below).
+    uint32_t stack_need = 1;
     float scene_abs = 0.0f;           // sum over axes of the largest |coordinate| of any box: scale of the traversal padding
     // Objects with a NaN/inf coordinate or radius.  The linear scan's answer for such an object depends on the
     // scan order (a NaN t is "accepted" and then lets every later hit through, world.rs:281-287), which no

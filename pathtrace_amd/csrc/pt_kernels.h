@@ -18,7 +18,7 @@ struct Run {
 
 // Optional BVH over the objects (pt_bvh.h); built on the host the first time a render asks for it.
 struct BvhView {
-    const uint4* nodes;      // 2 uint4 per internal node: the two child boxes on the 16-bit grid + child codes (pt_bvh.h)
+    const uint4* nodes;      // 4 uint4 (64 bytes) per internal node: up to four child boxes on the 16-bit grid + their child codes (pt_bvh.h)
     float grid_min[3], grid_cell[3];   // box coordinate = grid_min + q * grid_cell
     const float4* rec;       // 3 float4 per leaf slot (scan record of the primitive); the traversal reads e1, e2 of triangles here
     const float4* lead;      // 1 float4 per leaf slot = rec[3 * slot]: sphere (c, r^2) / triangle v0 -- a leaf's <= 4 are one 64-byte line

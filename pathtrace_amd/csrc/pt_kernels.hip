@@ -1276,34 +1276,44 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
         }
         const uint32_t low_water = next < n ? refill_below : 1u;
         do {
-            if (has && (int)node >= 0) {                 // internal node: test both child boxes
-                const uint4* nd = sc.bvh.nodes + 2u * node;
-                const uint4 qa = nd[0], qb = nd[1];
-                // child 0: words qa.x (lo.x | lo.y << 16), qa.y (lo.z | hi.x << 16), qa.z (hi.y | hi.z << 16)
-                float ax0 = __builtin_fmaf((float)(qa.x & 0xFFFFu), inv.x, bp.x), ax1 = __builtin_fmaf((float)(qa.y >> 16), inv.x, bm.x);
-                float ay0 = __builtin_fmaf((float)(qa.x >> 16), inv.y, bp.y), ay1 = __builtin_fmaf((float)(qa.z & 0xFFFFu), inv.y, bm.y);
-                float az0 = __builtin_fmaf((float)(qa.y & 0xFFFFu), inv.z, bp.z), az1 = __builtin_fmaf((float)(qa.z >> 16), inv.z, bm.z);
-                const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
-                const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
-                // child 1: words qa.w, qb.x, qb.y
-                ax0 = __builtin_fmaf((float)(qa.w & 0xFFFFu), inv.x, bp.x); ax1 = __builtin_fmaf((float)(qb.x >> 16), inv.x, bm.x);
-                ay0 = __builtin_fmaf((float)(qa.w >> 16), inv.y, bp.y); ay1 = __builtin_fmaf((float)(qb.y & 0xFFFFu), inv.y, bm.y);
-                az0 = __builtin_fmaf((float)(qb.x & 0xFFFFu), inv.z, bp.z); az1 = __builtin_fmaf((float)(qb.y >> 16), inv.z, bm.z);
-                const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
-                const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
-                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                const uint32_t c0 = qb.z, c1 = qb.w;
-                if (h0 && h1) {
-                    const bool swap = tn1 < tn0;               // nearer child first
-                    stk[sp * kBlock] = swap ? c0 : c1;
-                    ++sp;
-                    node = swap ? c1 : c0;
-                } else if (h0 || h1) {
-                    node = h0 ? c0 : c1;
+            if (has && (int)node >= 0) {                 // internal node: one 64-byte visit tests its (up to) four child boxes
+                const uint4* nd = sc.bvh.nodes + 4u * node;
+                const uint4 qa = nd[0], qb = nd[1], qc = nd[2], qd = nd[3];
+                // child c = three words (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16); entry distance of the
+                // padded box inside [t_min, closest], or "no hit"
+                auto slab = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t code, float& tn) -> bool {
+                    const float ax0 = __builtin_fmaf((float)(w0 & 0xFFFFu), inv.x, bp.x), ax1 = __builtin_fmaf((float)(w1 >> 16), inv.x, bm.x);
+                    const float ay0 = __builtin_fmaf((float)(w0 >> 16), inv.y, bp.y), ay1 = __builtin_fmaf((float)(w2 & 0xFFFFu), inv.y, bm.y);
+                    const float az0 = __builtin_fmaf((float)(w1 & 0xFFFFu), inv.z, bp.z), az1 = __builtin_fmaf((float)(w2 >> 16), inv.z, bm.z);
+                    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                         __builtin_fmaxf(__builtin_fminf(az0, az1), t_min));
+                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                     __builtin_fminf(__builtin_fmaxf(az0, az1), closest));
+                    return tn <= tf && code != 0xFFFFFFFFu;          // unused child slots carry the sentinel code
+                };
+                float t0, t1, t2, t3;
+                const bool h0 = slab(qa.x, qa.y, qa.z, qd.x, t0), h1 = slab(qa.w, qb.x, qb.y, qd.y, t1);
+                const bool h2 = slab(qb.z, qb.w, qc.x, qd.z, t2), h3 = slab(qc.y, qc.z, qc.w, qd.w, t3);
+                // Nearest child first, the others onto the stack far to near: a five-comparator network on (key, code) pairs,
+                // key = bits of the entry distance (t_min > 0: positive floats order like integers; with an unusual t_min <= 0
+                // the order is merely not by distance), misses sort last.  Branch-free: the three far codes are STORED
+                // unconditionally at the running stack top (a store above the top is harmless: the stack has three spare
+                // rows for it) and only the top moves conditionally -- as divergent branches this part cost more than the
+                // slab tests.
+                uint32_t k0 = h0 ? __float_as_uint(t0) : 0xFFFFFFFFu, k1 = h1 ? __float_as_uint(t1) : 0xFFFFFFFFu;
+                uint32_t k2 = h2 ? __float_as_uint(t2) : 0xFFFFFFFFu, k3 = h3 ? __float_as_uint(t3) : 0xFFFFFFFFu;
+                uint32_t c_near = qd.x, c1 = qd.y, c2 = qd.z, c3 = qd.w;
+                auto cx = [](uint32_t& kx, uint32_t& cxv, uint32_t& ky, uint32_t& cyv) {
+                    const bool sw = ky < kx;
+                    const uint32_t ka = sw ? ky : kx, kb = sw ? kx : ky, ca = sw ? cyv : cxv, cb = sw ? cxv : cyv;
+                    kx = ka; ky = kb; cxv = ca; cyv = cb;
+                };
+                cx(k0, c_near, k1, c1); cx(k2, c2, k3, c3); cx(k0, c_near, k2, c2); cx(k1, c1, k3, c3); cx(k1, c1, k2, c2);   // ascending: k0 nearest
+                stk[sp * kBlock] = c3; sp += k3 != 0xFFFFFFFFu ? 1u : 0u;
+                stk[sp * kBlock] = c2; sp += k2 != 0xFFFFFFFFu ? 1u : 0u;
+                stk[sp * kBlock] = c1; sp += k1 != 0xFFFFFFFFu ? 1u : 0u;
+                if (k0 != 0xFFFFFFFFu) {
+                    node = c_near;
                 } else {
                     --sp;
                     node = stk[sp * kBlock];
@@ -1477,7 +1487,7 @@ static int scene_mode(const SceneView& sc, uint32_t accel) {
     return accel ? kModeBvh : (sc.n_objs <= kSmallObjs ? kModeLds : kModeTiled);
 }
 static size_t scene_lds_bytes(const SceneView& sc, int mode) {
-    if (mode == kModeBvh) return (size_t)kBvhStack * kBlock * sizeof(uint32_t);
+    if (mode == kModeBvh) return (size_t)(kBvhStack + 3u) * kBlock * sizeof(uint32_t);   // + 3 rows: the traversal stores a visit's (up to) three far children before it knows how many there are
     return (mode == kModeLds ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
 }
 template <int MODE, bool DIFFUSE, bool LIST>
