@@ -31,10 +31,16 @@ struct Prim {
     uint32_t obj;
 };
 
+// primitives a leaf is filled to (<= kMaxLeaf, what the traversal unrolls for); measurement knob
+#ifndef PT_BVH_LEAF_TARGET
+#define PT_BVH_LEAF_TARGET 4
+#endif
+constexpr uint32_t kLeafTarget = PT_BVH_LEAF_TARGET;
+static_assert(kLeafTarget >= 1 && kLeafTarget <= kMaxLeaf, "leaf size");
 // levels an object-median subtree of m primitives needs below its root
 uint32_t median_levels(uint64_t m) {
     uint32_t l = 0;
-    while (m > kMaxLeaf) { m = (m + 1) / 2; ++l; }
+    while (m > kLeafTarget) { m = (m + 1) / 2; ++l; }
     return l;
 }
 
@@ -88,7 +94,7 @@ struct Builder {
             for (int k = 0; k < 3; ++k) { cb.lo[k] = std::min(cb.lo[k], prims[i].cen[k]); cb.hi[k] = std::max(cb.hi[k], prims[i].cen[k]); }
         }
         *box_out = box;
-        if (count <= kMaxLeaf) return make_leaf(first, count, depth);
+        if (count <= kLeafTarget) return make_leaf(first, count, depth);
 
         uint32_t mid = 0;
         bool split = false;

@@ -18,7 +18,10 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kDone = 0xFFFFFFFFu;      // stack sentinel / root of an empty scene (no leaf code: a leaf holds <= 4 primitives)
 constexpr uint32_t kMaxLeaf = 4;             // primitives per leaf
 constexpr uint32_t kWidth = 4;               // children per internal node
-constexpr uint32_t kStackDepth = 24;         // traversal stack entries per lane (LDS); the builder keeps the tree's stack need within it (<= 16 M objects)
+#ifndef PT_BVH_STACK
+#define PT_BVH_STACK 24
+#endif
+constexpr uint32_t kStackDepth = PT_BVH_STACK;         // traversal stack entries per lane (LDS); the builder keeps the tree's stack need within it (<= 16 M objects)
 constexpr uint32_t kTriangleBit = 0x80000000u;   // in leaf_ids: the primitive is a triangle
 
 // Internal node as the builder and the checker see it: up to kWidth children, each with the f32 box of its subtree.

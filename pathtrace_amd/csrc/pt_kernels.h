@@ -127,7 +127,10 @@ constexpr uint32_t kTileF4 = 1920;         // 30 KiB LDS tile (divisible by 3: w
 constexpr uint32_t kRefillBelow = 44;      // BVH traversal: hand out new rays when fewer lanes than this are tracing
 constexpr uint32_t kLeafBatch = 20;        // BVH traversal: test leaf primitives when at least this many lanes wait at a leaf
 constexpr uint32_t kBvhMaxLeaf = 4;        // primitives per BVH leaf the traversal unrolls for (= ptbvh::kMaxLeaf)
-constexpr uint32_t kBvhStack = 24;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 24 KiB per workgroup, 5 workgroups per CU
+#ifndef PT_BVH_STACK
+#define PT_BVH_STACK 24
+#endif
+constexpr uint32_t kBvhStack = PT_BVH_STACK;         // traversal stack entries per lane, in LDS (= ptbvh::kStackDepth): 24 KiB per workgroup, 5 workgroups per CU
 
 // One launch traces every path of a batch to its end.  grid = number of 256-thread workgroups
 // (4 queue segments each).  _exact / _fast: the two arithmetic modes of pt_device.h
