@@ -382,25 +382,15 @@ int pt_context_set_tuning(PtContext* c, const PtTuning* t) {
 int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     if (!c || (!objs && n)) return fail(PT_ERR_INVALID_ARG, "pt_scene_upload: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<float4> scan, shape(3 * (size_t)n + 1), mat(2 * (size_t)n + 1);
+    std::vector<float4> scan, shape(3 * (size_t)n + 1), mat(2 * (size_t)n + 1), obj_scan(3 * (size_t)n + 1);
+    std::vector<int> obj_ns(n + 1, 0);
     std::vector<ptk::Run> runs;
     std::vector<uint32_t> lights;
     for (uint32_t i = 0; i < n; ++i) {
         const PtObject& o = objs[i];
         if (o.shape_tag > PT_SHAPE_TRIANGLE) return fail(PT_ERR_INVALID_ARG, "object %u: bad shape_tag %u", i, o.shape_tag);
         if (o.mat_tag > PT_MAT_OREN_NAYAR) return fail(PT_ERR_INVALID_ARG, "object %u: bad mat_tag %u", i, o.mat_tag);
-        if (runs.empty() || runs.back().tag != o.shape_tag) {
-            ptk::Run r;
-            r.tag = o.shape_tag; r.first_obj = i; r.count = 0; r.off4 = (uint32_t)scan.size();
-            runs.push_back(r);
-        }
-        runs.back().count++;
-        {
-            float4 sc3[3];
-            int ns = 0;
-            shape_records(o, &shape[3 * (size_t)i], sc3, &ns);
-            scan.insert(scan.end(), sc3, sc3 + ns);
-        }
+        shape_records(o, &shape[3 * (size_t)i], &obj_scan[3 * (size_t)i], &obj_ns[i]);
         float p[6] = {(float)o.mat[0], (float)o.mat[1], (float)o.mat[2], (float)o.mat[3], (float)o.mat[4], (float)o.mat[5]};
         uint32_t emits = 0;
         if (o.mat_tag == PT_MAT_EMISSIVE) {
@@ -420,6 +410,33 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
         mat[2 * i] = make_float4(fb, p[0], p[1], p[2]);
         mat[2 * i + 1] = make_float4(p[3], p[4], p[5], 0.f);
         if (emits) lights.push_back(i);
+    }
+    // Scan array: runs of same-kind primitives in object order (the order decides closest-hit ties, world.rs:281-287).
+    // Two consecutive triangles whose records carry the SAME vertex v0 and the SAME plane normal bit for bit -- the two
+    // halves of a parallelogram fanned from one corner, like every wall of World::new() (world.rs:82-182) -- form a PAIR:
+    // determinant, t, the range test and the hit point are then literally the same numbers for both, and the scan
+    // computes them once (tripair_test, pt_kernels.hip).  Nothing changes in any result.
+    for (uint32_t i = 0; i < n;) {
+        const bool tri = objs[i].shape_tag == PT_SHAPE_TRIANGLE;
+        bool pair = false;
+        if (tri && i + 1 < n && objs[i + 1].shape_tag == PT_SHAPE_TRIANGLE) {
+            const float4 *a = &obj_scan[3 * (size_t)i], *b = &obj_scan[3 * (size_t)i + 3];
+            pair = std::memcmp(&a[0], &b[0], sizeof(float4)) == 0 && std::memcmp(&a[1], &b[1], 2 * sizeof(float)) == 0;
+        }
+        const uint32_t tag = !tri ? (uint32_t)ptk::kRunSphere : pair ? (uint32_t)ptk::kRunTrianglePair : (uint32_t)ptk::kRunTriangle;
+        if (runs.empty() || runs.back().tag != tag) {
+            ptk::Run r;
+            r.tag = tag; r.first_obj = i; r.count = 0; r.off4 = (uint32_t)scan.size();
+            runs.push_back(r);
+        }
+        runs.back().count++;
+        scan.insert(scan.end(), &obj_scan[3 * (size_t)i], &obj_scan[3 * (size_t)i] + obj_ns[i]);
+        if (pair) {      // the second triangle's barycentric gradients N1, N2 (its v0 and n are the first's)
+            const float4* b = &obj_scan[3 * (size_t)i + 3];
+            scan.push_back(make_float4(b[1].z, b[1].w, b[2].x, b[2].y));
+            scan.push_back(make_float4(b[2].z, b[2].w, 0.f, 0.f));
+        }
+        i += pair ? 2u : 1u;
     }
     int rc;
     if ((rc = c->scan.ensure(scan.size() + 1))) return rc;

@@ -9,12 +9,17 @@ namespace ptk {
 
 // One contiguous run of same-shape objects of World.objects, in object order
 // (the order decides closest-hit ties, src/world.rs:281-287).
+// kRunTrianglePair: entries of two consecutive triangles that share v0 and the plane normal bit for bit (the halves of a
+// parallelogram fanned from one corner): 5 float4 = the first triangle's record + (N1.xyz, N2.x), (N2.yz, -, -) of the
+// second; objects first_obj + 2k and first_obj + 2k + 1.
+enum { kRunSphere = 0, kRunTriangle = 1, kRunTrianglePair = 2 };
 struct Run {
-    uint32_t tag;        // SHAPE_SPHERE / SHAPE_TRIANGLE
+    uint32_t tag;        // kRunSphere / kRunTriangle (= the shape tags) / kRunTrianglePair
     uint32_t first_obj;  // object index of the run's first primitive
-    uint32_t count;      // primitives in the run
+    uint32_t count;      // entries in the run (primitives; pairs)
     uint32_t off4;       // offset of the run in the scan array, in float4 units
 };
+constexpr uint32_t run_entry_f4(uint32_t tag) { return tag == kRunSphere ? 1u : tag == kRunTriangle ? 3u : 5u; }
 
 // Optional BVH over the objects (pt_bvh.h); built on the host the first time a render asks for it.
 struct BvhView {

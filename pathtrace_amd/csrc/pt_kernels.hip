@@ -105,6 +105,38 @@ PT_DEV void triangle_test(float4 r0, float4 r1, float4 r2, f3 o, f3 d, float t_m
     id = obj;
 }
 
+// Two consecutive triangles with the same v0 and the same plane normal bit for bit (kRunTrianglePair, pt_kernels.h): what
+// triangle_test would compute twice -- determinant, t, the range test, the hit point -- is computed once.  The second test's
+// range check "t <= closest" holds either way: closest is unchanged, or the first triangle was just accepted at this t (and
+// the second, accepted too, wins the tie as the later object: world.rs:281-287).  Same results as two triangle_test calls.
+// Record: r0..r2 = the first triangle's, r3 = (N1.xyz, N2.x), r4 = (N2.y, N2.z, -, -) of the second.
+template <bool ANY = false>
+PT_DEV void tripair_test(float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
+    const f3 n = mk(r0.w, r1.x, r1.y);
+    const float det = dot(d, n);
+    if (__builtin_fabsf(det) < 1e-8f) return;
+    const f3 s = o - mk(r0.x, r0.y, r0.z);
+    const float t = pt_div(-dot(s, n), det);
+    if (t < t_min || t > closest) return;
+    const f3 p = madd(d, t, s);
+    const float u0 = dot(p, mk(r1.z, r1.w, r2.x));
+    if (u0 >= 0.0f && u0 <= 1.0f) {
+        const float v0 = dot(p, mk(r2.y, r2.z, r2.w));
+        if (!(v0 < 0.0f || u0 + v0 > 1.0f)) {
+            if (ANY) { id = 0; return; }
+            closest = t; id = obj;
+        }
+    }
+    const float u1 = dot(p, mk(r3.x, r3.y, r3.z));
+    if (u1 >= 0.0f && u1 <= 1.0f) {
+        const float v1 = dot(p, mk(r3.w, r4.x, r4.y));
+        if (!(v1 < 0.0f || u1 + v1 > 1.0f)) {
+            if (ANY) { id = 0; return; }
+            closest = t; id = obj + 1;
+        }
+    }
+}
+
 // sphere_test in two halves: the part every sphere pays (half_b, discriminant) and the part an accepted discriminant
 // pays.  Same operations in the same order per sphere; split so that a group of four can run the first halves
 // back to back (four independent dependency chains) before the divergent second halves.
@@ -167,10 +199,15 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
             sphere_test<false, ANY>(s3, o, d, t_min, closest, id, first_obj + (int)i + 3);
         }
         for (; i < n; ++i) sphere_test<false, ANY>(p[i], o, d, t_min, closest, id, first_obj + (int)i);
-    } else {
+    } else if (tag == kRunTriangle) {
         for (uint32_t i = 0; i < n; ++i) {
             float4 a0 = p[3 * i], a1 = p[3 * i + 1], a2 = p[3 * i + 2];
             triangle_test<false, ANY>(a0, a1, a2, o, d, t_min, closest, id, first_obj + (int)i);
+        }
+    } else {
+        for (uint32_t i = 0; i < n; ++i) {
+            float4 a0 = p[5 * i], a1 = p[5 * i + 1], a2 = p[5 * i + 2], a3 = p[5 * i + 3], a4 = p[5 * i + 4];
+            tripair_test<ANY>(a0, a1, a2, a3, a4, o, d, t_min, closest, id, first_obj + 2 * (int)i);
         }
     }
 }
@@ -243,7 +280,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
         // from it) in scalar registers
         run.tag = __builtin_amdgcn_readfirstlane(run.tag); run.first_obj = __builtin_amdgcn_readfirstlane(run.first_obj);
         run.count = __builtin_amdgcn_readfirstlane(run.count); run.off4 = __builtin_amdgcn_readfirstlane(run.off4);
-        const uint32_t per = run.tag == SHAPE_SPHERE ? 1u : 3u;
+        const uint32_t per = run_entry_f4(run.tag);
         if (SMALL) {
             scan_run<false, ANY>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
         } else {
@@ -255,7 +292,7 @@ PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_ma
                 const float4* src = sc.scan_global + run.off4 + p0 * per;
                 for (uint32_t k = threadIdx.x; k < np * per; k += kBlock) tile[k] = src[k];
                 __syncthreads();
-                scan_run<true, ANY>(tile, run.tag, np, (int)(run.first_obj + p0), o, d, t_min, closest, id);
+                scan_run<true, ANY>(tile, run.tag, np, (int)(run.first_obj + p0 * (run.tag == kRunTrianglePair ? 2u : 1u)), o, d, t_min, closest, id);
             }
         }
     }

@@ -177,6 +177,59 @@ def test_hit_scene_kernel_against_oracle(pt, orc, gpu_ctx, scene, arg):
     assert np.array_equal(ids_c, ids_c32)
 
 
+def _quad_scene(pt, rng, n_quads, n_single, n_spheres):
+    """Parallelogram quads as two triangles fanned from one corner (the pairs the scan tests together), single triangles
+    and spheres, shuffled so that pair runs, triangle runs and sphere runs alternate; a quad's halves stay adjacent."""
+    groups = []
+    for _ in range(n_quads):
+        a = rng.uniform([-0.9, -0.9, -2.9], [0.9, 0.9, -1.1])
+        e1, e2 = rng.normal(size=3) * 0.35, rng.normal(size=3) * 0.35
+        b, c, d = a + e1, a + e1 + e2, a + e2
+        col = list(rng.uniform(0.2, 0.9, 3))
+        groups.append([(1, list(a) + list(b) + list(c), 0, col), (1, list(a) + list(c) + list(d), 0, col)])
+    for _ in range(n_single):
+        v = rng.uniform([-0.9, -0.9, -2.9], [0.9, 0.9, -1.1], size=(3, 3))
+        groups.append([(1, list(v.ravel()), 0, list(rng.uniform(0.2, 0.9, 3)))])
+    for k in range(n_spheres):
+        c = rng.uniform([-0.8, -0.8, -2.8], [0.8, 0.8, -1.2])
+        groups.append([(0, list(c) + [float(rng.uniform(0.05, 0.25))], 1 if k == 0 else 0, [9.0, 9.0, 9.0] if k == 0 else [0.7, 0.7, 0.7])])
+    order = rng.permutation(len(groups))
+    return pt.make_objects([spec for g in order for spec in groups[g]])
+
+
+@pytest.mark.parametrize("n_quads,n_single,n_spheres", [(6, 0, 1), (5, 7, 6), (70, 40, 30)])   # the last one: > 128 objects, tiled scan
+def test_triangle_pairs_are_tested_like_two_triangles(pt, orc, gpu_ctx, n_quads, n_single, n_spheres):
+    """Consecutive triangles with the same v0 and plane normal (halves of a parallelogram; every wall of World::new())
+    share one determinant / t / range test / hit point in the scan (tripair_test).  Same ids and t bits as the f32
+    oracle, which tests every triangle on its own -- on random rays, on rays aimed at the shared diagonal (both halves
+    accept: the later object wins, world.rs:281-287), at the corners and along the planes; with a finite t_max; through the
+    BVH; and as a film."""
+    rng = np.random.default_rng(500 + n_quads)
+    objs = _quad_scene(pt, rng, n_quads, n_single, n_spheres)
+    gpu_ctx.upload(objs)
+    n = 60_000
+    o = np.stack([rng.uniform(-0.95, 0.95, n), rng.uniform(-0.95, 0.95, n), rng.uniform(-2.9, 1.9, n)], 1)
+    d = rng.normal(size=(n, 3))
+    # rays through points of the quads' diagonals, corners and edges (exact in f64, rounded by the f32 conversion)
+    tri = [np.array(ob.shape[:9]).reshape(3, 3) for ob in objs if ob.shape_tag == 1]
+    aimed = []
+    for v in tri[:200]:
+        for w in ([1, 0, 0], [0, 0, 1], [0.5, 0, 0.5], [0.25, 0, 0.75], [0.5, 0.5, 0], [1 / 3, 1 / 3, 1 / 3]):
+            tgt = np.array(w) @ v
+            org = rng.uniform([-0.9, -0.9, -0.9], [0.9, 0.9, 1.5])
+            aimed.append(np.concatenate([org, tgt - org]))
+    rays = np.concatenate([np.concatenate([o, d], 1), np.array(aimed)], 0)
+    for t_max in (float("inf"), 1.7):
+        ids, t = gpu_ctx.debug_hit_scene(rays, 0.001, t_max, exact_math=1)
+        ids32, t32, _, _ = orc.hit_scene(objs, rays, 0.001, t_max, F32)
+        assert np.array_equal(ids, ids32)
+        assert np.array_equal(t[ids >= 0], t32[ids >= 0].astype(np.float32))
+        ids_b, t_b = gpu_ctx.debug_hit_scene(rays, 0.001, t_max, exact_math=1, accel=1)
+        assert np.array_equal(ids_b, ids) and np.array_equal(t_b[ids >= 0], t[ids >= 0])
+    cam = pt.camera_new(width=96, height=64)
+    _check(pt, orc, gpu_ctx, objs, cam, pt.default_params(spp=4), f64_frac=0.97, fast_close=0.97, vert_rel=1e-2)
+
+
 def test_pt_render_host_buffers_entry(pt, orc, gpu_ctx):
     """pt_render(): the one-shot entry with host buffers (= src/main.rs:43-60)."""
     objs = pt.builtin_scene(1)
