@@ -970,8 +970,7 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE ? kRegenWavesDiffuse : kRegenW
 //     of kMatsAll), then the closest-hit scan of their NEXT vertex: Mirror again (a path inside the sphere) -> back onto
 //     the special stack with its (id, t); anything else -> onto the wave's PLAIN stack, from which the regeneration step
 //     of the plain iterations takes entries before it takes camera rays.  Then the plain paths come back into the lanes.
-// Both stacks share one 128-entry region per wave in global memory (L2-resident: 18 KB per wave incl. the parking and
-// staging slots), special growing up, plain growing down.  They cannot collide: paths enter a wave only through camera-ray
+// Both stacks share one 128-entry region per wave in global memory (L2-resident: 14 KB per wave incl. the parking slots; the staging slots of a batch are in LDS), special growing up, plain growing down.  They cannot collide: paths enter a wave only through camera-ray
 // regeneration, which happens only when the plain stack is empty and (batches run whenever >= 64 specials wait) at most
 // 63 specials wait, so lanes + stacks never hold more than 127 paths.  No atomics, no other wave involved.
 // Same per-vertex functions on the same inputs as every other form (a path's arithmetic does not depend on which lane
@@ -979,7 +978,7 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE ? kRegenWavesDiffuse : kRegenW
 constexpr int kWaitVm0 = 0x0F70;                                 // s_waitcnt vmcnt(0) alone (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 constexpr uint32_t kXq = 128;                                    // exchange entries per wave
 constexpr uint32_t kXqEntryF4 = 5;                               // stack entry: 4 float4 of path state (layout of Queue) + (bits(id), t, -, -)
-constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4 + 2u * 64u * 4u;   // the stacks + 64 parking + 64 staging slots of 4 float4
+constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4 + 64u * 4u;   // the stacks + 64 parking slots of 4 float4
 static_assert(kXqF4PerWave == kRegenSplitF4PerWave, "pt_kernels.h sizes the buffer");
 // One wave-uniform base pointer (two scalar registers); entry-major, so the planes of an entry are immediate offsets of
 // ONE address -- with plane-major arrays the compiler kept a scalar base per plane (24 SGPRs more than the kernel has).
@@ -987,7 +986,6 @@ struct XWave {
     float4* b;
     PT_DEV float4* entry(uint32_t e) const { return b + e * kXqEntryF4; }                  // [0..3] state, [4] = (bits(id), t, -, -) of a special entry's pending vertex
     PT_DEV float4* park(uint32_t l) const { return b + kXq * kXqEntryF4 + l * 4u; }        // the wave's 64 plain paths while a batch of specials runs
-    PT_DEV float4* stage(uint32_t l) const { return b + kXq * kXqEntryF4 + 256u + l * 4u; }   // a batch's survivors while the scan of their next vertex decides their stack
 };
 PT_DEV XWave xwave(float4* base, uint32_t wave_uniform) {
     XWave x;
@@ -1009,11 +1007,13 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     extern __shared__ float4 lds[];
     __shared__ float4 s_pool_d[kBlock / 64][kPool];
     __shared__ uint32_t s_pool_s[kBlock / 64][kPool];
+    __shared__ float4 s_stage[kBlock / 64][4][64];       // a batch's survivors while the scan of their next vertex decides their stack (plane-major: conflict-free)
     const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;
     float4* const pool_d = s_pool_d[wib];
     uint32_t* const pool_s = s_pool_s[wib];
+    float4 (*const stage)[64] = s_stage[wib];
     const uint32_t n_first = a.n_first;
     const uint32_t n_chunks = (n_first + 63u) >> 6;
     const uint32_t W = a.film_w;
@@ -1194,9 +1194,12 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 }
                 // the survivors' next vertex: Mirror again (a path inside the sphere) or not?  Their state waits in the
                 // staging slots meanwhile; the scan needs the ray only.
-                uint32_t ls = lane;
-                asm volatile("" : "+v"(ls));
-                if (qalive) store_entry(x.stage(ls), q);
+                if (qalive) {
+                    stage[0][lane] = make_float4(q.o.x, q.o.y, q.o.z, q.d.x);
+                    stage[1][lane] = make_float4(q.d.y, q.d.z, __uint_as_float((q.yl << 16) | q.px), __uint_as_float((q.s_local << 16) | q.depth));
+                    stage[2][lane] = make_float4(q.beta.x, q.beta.y, q.beta.z, q.pdf_prev);
+                    stage[3][lane] = make_float4(q.L.x, q.L.y, q.L.z, q.eta_in);
+                }
                 const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
                 asm volatile("" ::: "memory");
                 int id2; float t2;
@@ -1205,11 +1208,9 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const bool plain2 = qalive && !spec2;
                 const unsigned long long m_s = __ballot(spec2), m_p = __ballot(plain2);
                 const uint32_t n_p = (uint32_t)__popcll(m_p);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 if (qalive) {
                     const uint32_t dst = spec2 ? sq_cnt + lane_rank(m_s) : kXq - pq_cnt - n_p + lane_rank(m_p);
-                    const float4* sg = x.stage(ls);
-                    const float4 s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3];
+                    const float4 s0 = stage[0][lane], s1 = stage[1][lane], s2 = stage[2][lane], s3 = stage[3][lane];
                     float4* de = x.entry(dst);
                     de[0] = s0; de[1] = s1; de[2] = s2; de[3] = s3;
                     if (spec2) de[4] = make_float4(__int_as_float(id2), t2, 0.0f, 0.0f);
