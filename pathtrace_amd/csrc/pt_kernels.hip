@@ -1250,6 +1250,9 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
 // with has_ray == 0 is skipped; t_max itself may be anything, also negative or NaN -- the scan's semantics
 // decide), else plane1[slot] = (d.y, d.z, -, -) and t_max = inf.  ANY: out[slot].z = 1 if anything is hit, else 0 (visibility).  Otherwise
 // out[slot].xy = (id, t) of the closest hit.  Semantics of one ray: bvh_scan.
+#ifndef PT_BVH_POSTPONE
+#define PT_BVH_POSTPONE 1
+#endif
 template <bool TMAX_IN_RAY, bool ANY>
 PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plane0, const float4* __restrict__ plane1,
                              float4* __restrict__ out, uint32_t n, float t_min, uint32_t refill_below, uint32_t leaf_batch) {
@@ -1269,6 +1272,9 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
     const f3 gcell = mk(sc.bvh.grid_cell[0], sc.bvh.grid_cell[1], sc.bvh.grid_cell[2]);
     float closest = 0.0f;
     int id = -1;
+#if PT_BVH_POSTPONE
+    uint32_t pend = 0xFFFFFFFFu;                // a leaf this lane has put aside (none: the sentinel)
+#endif
     for (;;) {
         // ---- hand the next slots to the idle lanes, in lane order
         const unsigned long long idle = __ballot(!has);
@@ -1357,11 +1363,25 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                     node = stk[sp * kBlock];
                 }
             }
+#if PT_BVH_POSTPONE
+            // A lane that reaches a leaf puts it aside (one per lane) and goes on with its stack: it keeps working on inner
+            // nodes while the wave collects enough leaves for a dense batch of primitive tests.  (The tests run later than
+            // in stack order, so `closest` may shrink later: a few more visits, never another answer.)
+            if (has && pend == 0xFFFFFFFFu && (int)node < 0 && node != 0xFFFFFFFFu) {
+                pend = node;
+                --sp;
+                node = stk[sp * kBlock];
+            }
+            const bool at_leaf = has && pend != 0xFFFFFFFFu;
+            const uint32_t leaf = pend;
+#else
             const bool at_leaf = has && (int)node < 0 && node != 0xFFFFFFFFu;
+            const uint32_t leaf = node;
+#endif
             const unsigned long long leafs = __ballot(at_leaf);
             if (leafs != 0ull && ((uint32_t)__popcll(leafs) >= leaf_batch || __ballot(has && (int)node >= 0) == 0ull)) {
                 if (at_leaf) {
-                    const uint32_t first = node & 0x0FFFFFFFu, cnt = ((node >> 28) & 7u) + 1u;
+                    const uint32_t first = leaf & 0x0FFFFFFFu, cnt = ((leaf >> 28) & 7u) + 1u;
                     // all ids (one aligned 16-byte load) and lead records (one 64-byte line) requested before the
                     // first test: one memory latency per leaf
                     const uint4 idv = *reinterpret_cast<const uint4*>(sc.bvh.ids + first);
@@ -1381,15 +1401,24 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
                             }
                         }
                     }
+#if PT_BVH_POSTPONE
+                    pend = 0xFFFFFFFFu;
+                    if (ANY && id >= 0) node = 0xFFFFFFFFu;
+#else
                     if (ANY && id >= 0) {
                         node = 0xFFFFFFFFu;
                     } else {
                         --sp;
                         node = stk[sp * kBlock];
                     }
+#endif
                 }
             }
+#if PT_BVH_POSTPONE
+            if (has && node == 0xFFFFFFFFu && pend == 0xFFFFFFFFu) {   // this ray is done
+#else
             if (has && node == 0xFFFFFFFFu) {            // this ray is done
+#endif
                 if (ANY) out[slot].z = id >= 0 ? 1.0f : 0.0f;
                 else *reinterpret_cast<float2*>(&out[slot]) = make_float2(__int_as_float(id), closest);
                 has = false;
