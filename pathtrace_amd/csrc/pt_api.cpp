@@ -787,6 +787,8 @@ int pt_sync(PtContext* c) {
         c->stats.primary_kernel_ms = pms;
         c->stats.max_depth_reached = (uint32_t)c->h_dstats[2];
         c->stats_pending = false;
+        if (c->h_dstats[7] != 0)     // a kernel found one of its own invariants violated: the film is not to be trusted
+            return fail(PT_ERR_HIP, "internal: the exchange stacks of k_paths_regen_split overflowed (please report; PtTuning.level0_form = 1 avoids the kernel)");
     }
     return PT_OK;
 }

@@ -1026,6 +1026,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     uint32_t pool_head = 0, pool_cnt = 0;
     bool exhausted = false;
     uint32_t sq_cnt = 0, pq_cnt = 0;       // wave-uniform: special entries [0, sq_cnt), plain entries [kXq - pq_cnt, kXq)
+    bool overflow = false;                 // wave-uniform: the stacks met (cannot happen, see above; reported instead of corrupting paths)
     uint32_t wave_shadow = 0, wave_vertices = 0;
     uint32_t dmax = 0;
     PathState p = parked_state();
@@ -1117,6 +1118,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                     id = -1;
                 }
                 sq_cnt += (uint32_t)__popcll(spm);
+                overflow = overflow || sq_cnt + pq_cnt > kXq;
             }
             const bool active = alive;
             const uint32_t kx = p.px, py = image_row(a.tile, p.yl);
@@ -1217,6 +1219,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 }
                 sq_cnt += (uint32_t)__popcll(m_s);
                 pq_cnt += n_p;
+                overflow = overflow || sq_cnt + pq_cnt > kXq;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             } while (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work()));
             asm volatile("" : "+v"(ln));
@@ -1231,6 +1234,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
+        if (overflow) atomicMax(&a.stats[7], 1ull);      // pt_sync turns it into an error
     }
 }
 
