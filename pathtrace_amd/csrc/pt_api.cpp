@@ -121,6 +121,7 @@ struct PtContext {
     hipStream_t stream = nullptr;
     // scene
     DevBuf<float4> scan, shape, mat, blob;
+    DevBuf<float4> shape_x, mat_x, blob_x;   // the exact_math = 1 copies: the records carry per-object constants evaluated in that mode (k_scene_setup)
     DevBuf<ptk::Run> runs;
     DevBuf<uint32_t> lights;
     ptk::SceneView view{};
@@ -225,6 +226,16 @@ void shape_records(const PtObject& o, float4 gather[3], float4 scan[3], int* n_s
         ptbvh::triangle_scan_record(gather[0], gather[1], gather[2], scan);       // plane + barycentric gradients (pt_bvh.h)
         *n_scan = 3;
     }
+}
+
+// The scene as a launch in the given arithmetic mode sees it (the records carry constants evaluated in that mode)
+ptk::SceneView view_for(const PtContext* c, uint32_t exact_math) {
+    ptk::SceneView v = c->view;
+    if (exact_math) {
+        v.shape = c->shape_x.p; v.mat = c->mat_x.p;
+        if (v.blob) v.blob = c->blob_x.p;
+    }
+    return v;
 }
 
 // Build and upload the BVH of the uploaded scene (once per scene).
@@ -442,12 +453,21 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     if ((rc = c->scan.ensure(scan.size() + 1))) return rc;
     if ((rc = c->shape.ensure(shape.size()))) return rc;
     if ((rc = c->mat.ensure(mat.size()))) return rc;
+    if ((rc = c->shape_x.ensure(shape.size()))) return rc;
+    if ((rc = c->mat_x.ensure(mat.size()))) return rc;
     if ((rc = c->runs.ensure(runs.size() + 1))) return rc;
     if ((rc = c->lights.ensure(lights.size() + 1))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));   // the previous scene may still be in use
     if (!scan.empty()) HIP_TRY(hipMemcpy(c->scan.p, scan.data(), scan.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->shape.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat.p, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->shape_x.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->mat_x.p, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+    // a triangle's unit normal and 1 / area, once per object and arithmetic mode, by the device's own expressions
+    ptk::launch_scene_setup_fast(c->shape.p, c->mat.p, n, c->stream);
+    ptk::launch_scene_setup_exact(c->shape_x.p, c->mat_x.p, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (!runs.empty()) HIP_TRY(hipMemcpy(c->runs.p, runs.data(), runs.size() * sizeof(ptk::Run), hipMemcpyHostToDevice));
     if (!lights.empty()) HIP_TRY(hipMemcpy(c->lights.p, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->view.scan = c->scan.p; c->view.shape = c->shape.p; c->view.mat = c->mat.p;
@@ -465,8 +485,14 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
             for (size_t k = 0; k < 4 && i + k < lights.size(); ++k) w[k] = lights[i + k];
             float4 f; std::memcpy(&f, w, sizeof f); blob.push_back(f);
         }
-        if ((rc = c->blob.ensure(blob.size() + 1))) return rc;
-        if (!blob.empty()) HIP_TRY(hipMemcpy(c->blob.p, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
+        if ((rc = c->blob.ensure(blob.size() + 1)) || (rc = c->blob_x.ensure(blob.size() + 1))) return rc;
+        for (float4* dst : {c->blob.p, c->blob_x.p}) {
+            if (!blob.empty()) HIP_TRY(hipMemcpy(dst, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
+            // shape and material records as k_scene_setup left them in this mode's arrays
+            const bool x = dst == c->blob_x.p;
+            if (n) HIP_TRY(hipMemcpy(dst + scan.size(), x ? c->shape_x.p : c->shape.p, 3 * (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice));
+            if (n) HIP_TRY(hipMemcpy(dst + scan.size() + 3 * (size_t)n, x ? c->mat_x.p : c->mat.p, 2 * (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice));
+        }
         c->view.blob = c->blob.p;
         c->view.blob_f4 = (uint32_t)blob.size();
     }
@@ -628,7 +654,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         a.tile.band_stride = br * band_count;
         a.tile.band_first = prm->band_index * br;
     }
-    a.sc = c->view;
+    a.sc = view_for(c, prm->exact_math);
     for (int k = 0; k < 3; ++k) {
         a.cam.origin[k] = (float)cam->origin[k]; a.cam.lower_left[k] = (float)cam->lower_left[k];
         a.cam.horizontal[k] = (float)cam->horizontal[k]; a.cam.vertical[k] = (float)cam->vertical[k];
@@ -830,7 +856,7 @@ int debug_hit_impl(PtContext* c, const double* rays, uint32_t n, double t_min, d
     if (out_rec && (rc = d_rec.ensure(8 * (size_t)n))) return rc;
     if (accel && (rc = d_scratch.ensure(3 * (size_t)n))) return rc;
     HIP_TRY(hipMemcpy(d_r.p, r6.data(), r6.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (exact_math) ptk::launch_debug_hit_exact(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, d_rec.p, c->stream);
+    if (exact_math) ptk::launch_debug_hit_exact(view_for(c, 1), accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, d_rec.p, c->stream);
     else ptk::launch_debug_hit_fast(c->view, accel, d_r.p, n, (float)t_min, (float)t_max, d_scratch.p, d_id.p, d_t.p, d_rec.p, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -857,7 +883,7 @@ int debug_fn(PtContext* c, uint32_t op, uint32_t obj, const std::vector<float>& 
     if (!in.empty()) HIP_TRY(hipMemcpy(c->fn_in.p, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice));
     if (words) HIP_TRY(hipMemcpy(c->fn_words.p, words, 4 * (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
     ptk::DebugFnArgs a{};
-    a.sc = c->view;
+    a.sc = view_for(c, exact_math);
     if (cam) {
         for (int k = 0; k < 3; ++k) {
             a.cam.origin[k] = (float)cam->origin[k]; a.cam.lower_left[k] = (float)cam->lower_left[k];

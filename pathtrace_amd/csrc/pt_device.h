@@ -160,9 +160,14 @@ PT_DEV float u01(uint32_t r) { return __uint_as_float(__builtin_amdgcn_alignbit(
 // ------------------------------------------------------------------ scene records
 // shape record, 3 float4 per object:
 //   sphere   : r0 = (cx, cy, cz, radius), r1 = (1/radius, -, -, -)
-//   triangle : r0 = (v0, -), r1 = (e1 = v1-v0, -), r2 = (e2 = v2-v0, -)
+//   triangle : r0 = (v0, nx), r1 = (e1 = v1-v0, ny), r2 = (e2 = v2-v0, nz)      n = normalize(e1 x e2), the geometric normal
 // material record, 2 float4 per object:
-//   m0 = (mat_tag | shape_tag<<8 | emits<<16 as bits, p0, p1, p2), m1 = (p3, p4, p5, -)
+//   m0 = (mat_tag | shape_tag<<8 | emits<<16 as bits, p0, p1, p2), m1 = (p3, p4, p5, triangle: 1/area)
+// The triangle's unit normal (shape.rs:195, :213) and 1/area (:214-215, :225) are the same numbers at every hit and
+// every light sample: k_scene_setup evaluates them ONCE per object at pt_scene_upload, on the device, with the very
+// expressions of this header and in both arithmetic modes (triangle_constants below; each mode has its own copy of
+// the records), so they are bit for bit what evaluating them per vertex gave -- 16 + 20 instructions and five
+// transcendentals less per vertex of the reference scene.
 //   lambert/emissive: p0..2 = colour; mirror: p0 = roughness, p1..3 = colour, p4 = metallic, p5 = ior;
 //   oren-nayar: p0..2 = albedo, p3 = A, p4 = B (material.rs:182-193)
 enum { SHAPE_SPHERE = 0, SHAPE_TRIANGLE = 1 };
@@ -210,8 +215,7 @@ PT_DEV Hit finish_hit(const float4* __restrict__ shape, int id, uint32_t shape_t
     if (shape_tag == SHAPE_SPHERE) {
         outward = (h.point - mk(r0.x, r0.y, r0.z)) * shape[3 * id + 1].x;   // shape.rs:86; r1.x = 1/radius
     } else {
-        float4 r1 = shape[3 * id + 1], r2 = shape[3 * id + 2];
-        outward = normalize(cross(mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z)));   // shape.rs:195
+        outward = mk(r0.w, shape[3 * id + 1].w, shape[3 * id + 2].w);           // shape.rs:195, from triangle_constants
     }
     face_forward(h, outward, d);
     return h;
@@ -270,7 +274,14 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
 }
 // TriangleShape::sample_surface_from_point, shape.rs:200-242; dir / dist as above (here the reference itself forms
 // them, :218-221, and rendering.rs:58-60 forms the same values again)
-PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 target, float r1, float r2,
+// normal / pdf_area: the triangle's unit normal and 1 / area (shape.rs:213-215,225), from triangle_constants
+PT_DEV void triangle_constants(f3 e1, f3 e2, f3& normal, float& pdf_area) {
+    f3 cr = cross(e1, e2);
+    normal = normalize(cr);
+    float area = length(cr) * 0.5f;
+    pdf_area = pt_rcp(area);
+}
+PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 normal, float pdf_area, f3 from, bool with_target, f3 target, float r1, float r2,
                             f3& point, float& pdf_omega, f3& dir, float& dist) {
     if (with_target) {
         point = target;
@@ -280,9 +291,6 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 t
         float v = r2 * sqrt_r1;
         point = madd(e2, v, madd(e1, u, v0));
     }
-    f3 cr = cross(e1, e2);
-    f3 normal = normalize(cr);
-    float area = length(cr) * 0.5f;
     f3 to_light = point - from;
 #if PT_MATH_EXACT || !defined(PT_RSQ_NORMALIZE)
     float d = length(to_light);
@@ -292,20 +300,19 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 from, bool with_target, f3 t
     f3 light_dir = normalize_len(to_light, d);
 #endif
     float cos_light = __builtin_fabsf(dot(normal, -light_dir));
-    float pdf_area = pt_rcp(area);
     pdf_omega = cos_light > 1e-8f ? pt_div(pdf_area * (d * d), cos_light) : 1e-8f;
     dist = d;
     dir = d > 0.0f ? light_dir : to_light;           // Vector3::normalize leaves a zero vector as it is (math.rs:48-51)
 }
-PT_DEV void shape_sample(const float4* __restrict__ shape, int id, uint32_t shape_tag, f3 from, bool with_target,
-                         f3 target, float r1, float r2, f3& point, float& pdf_omega, f3& dir, float& dist) {
+PT_DEV void shape_sample(const float4* __restrict__ shape, const float4* __restrict__ mat, int id, uint32_t shape_tag, f3 from,
+                         bool with_target, f3 target, float r1, float r2, f3& point, float& pdf_omega, f3& dir, float& dist) {
     float4 r0 = shape[3 * id];
     if (shape_tag == SHAPE_SPHERE) {
         sphere_sample(r0, from, with_target, target, r1, r2, point, pdf_omega, dir, dist);
     } else {
         float4 q1 = shape[3 * id + 1], q2 = shape[3 * id + 2];
-        triangle_sample(mk(r0.x, r0.y, r0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), from, with_target, target,
-                        r1, r2, point, pdf_omega, dir, dist);
+        triangle_sample(mk(r0.x, r0.y, r0.z), mk(q1.x, q1.y, q1.z), mk(q2.x, q2.y, q2.z), mk(r0.w, q1.w, q2.w), mat[2 * id + 1].w,
+                        from, with_target, target, r1, r2, point, pdf_omega, dir, dist);
     }
 }
 

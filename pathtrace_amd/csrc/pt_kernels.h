@@ -152,6 +152,10 @@ constexpr uint32_t kRegenWavesDiffuse = PT_REGEN_WAVES_DIFFUSE, kRegenWavesGener
 constexpr uint32_t kRegenSplitF4PerWave = 128u * 5u + 64u * 4u;
 // chunk counters of k_paths_regen: chunk_counter[c * kRegenCounterStride], c < kRegenCounters (256 bytes apart)
 constexpr uint32_t kRegenCounters = 8, kRegenCounterStride = 64;
+// pt_scene_upload: per-object constants written into the shape / material records (k_scene_setup), one call per arithmetic
+// mode on that mode's copy of the records
+void launch_scene_setup_exact(float4* shape, float4* mat, uint32_t n_objs, hipStream_t st);
+void launch_scene_setup_fast(float4* shape, float4* mat, uint32_t n_objs, hipStream_t st);
 void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);
 void launch_paths_fast(const BounceArgs& a, uint32_t grid, hipStream_t st);
 

@@ -432,7 +432,7 @@ PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, ui
     const Mat lm = load_mat(sc.mat, lobj);
     assume_mats<DIFFUSE>(lm.tag);
     float pdf_shape;
-    shape_sample(sc.shape, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape, dir, dist);
+    shape_sample(sc.shape, sc.mat, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape, dir, dist);
     emission = lm.color;                                                          // world.rs:259
     pdf = sc.n_lights == 1u ? pdf_shape : pt_div(pdf_shape, (float)sc.n_lights);  // world.rs:260 (x/1 == x)
 }
@@ -461,7 +461,7 @@ PT_DEV void vertex_begin(const SceneRef& sc, PathState& p, bool active, int id, 
                 // emitter reached by a BSDF-sampled ray: its MIS weight (vertex_end) is against the light pdf of
                 // this point seen from the previous vertex = this ray's origin (rendering.rs:107-116)
                 f3 sp, sd; float sl;
-                shape_sample(sc.shape, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, v.emit_pdf_shape, sd, sl);
+                shape_sample(sc.shape, sc.mat, id, v.m.shape_tag, p.o, true, v.hit.point, 0.f, 0.f, sp, v.emit_pdf_shape, sd, sl);
             }
             v.alive = false;
         }
@@ -1788,7 +1788,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_fn(DebugFnArgs a) {
         const f3 from = mk(in[0], in[1], in[2]);
         f3 point, dir = mk(0.f, 0.f, 0.f); float pdf, dist = 0.0f;
         const bool with_target = in[8] != 0.0f;
-        shape_sample(sc.shape, (int)a.obj, m.shape_tag, from, with_target, mk(in[3], in[4], in[5]), in[6], in[7], point, pdf, dir, dist);
+        shape_sample(sc.shape, sc.mat, (int)a.obj, m.shape_tag, from, with_target, mk(in[3], in[4], in[5]), in[6], in[7], point, pdf, dir, dist);
         if (with_target) {                   // look-ahead form: the sampler produces no direction; report the point's
             const f3 to_light = point - from;
             dir = normalize(to_light); dist = length(to_light);
@@ -1809,9 +1809,30 @@ __global__ void __launch_bounds__(kBlock) k_debug_fn(DebugFnArgs a) {
         out[6] = u01(dc[0]); out[7] = u01(dc[1]);
     }
 }
+
+// ------------------------------------------------------------------ per-object constants (pt_scene_upload)
+// One thread per object: a triangle's unit normal into the spare w components of its shape record, 1 / area into the spare
+// component of its material record (pt_device.h "scene records").  Evaluated by the expressions the per-vertex code
+// used to run (triangle_constants), in this translation unit's arithmetic mode, on that mode's copy of the records.
+__global__ void k_scene_setup(float4* shape, float4* mat, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bits = __float_as_uint(mat[2 * i].x);
+    if (((bits >> 8) & 0xFFu) != SHAPE_TRIANGLE) return;
+    float4 r0 = shape[3 * i], r1 = shape[3 * i + 1], r2 = shape[3 * i + 2];
+    f3 normal; float pdf_area;
+    triangle_constants(mk(r1.x, r1.y, r1.z), mk(r2.x, r2.y, r2.z), normal, pdf_area);
+    r0.w = normal.x; r1.w = normal.y; r2.w = normal.z;
+    shape[3 * i] = r0; shape[3 * i + 1] = r1; shape[3 * i + 2] = r2;
+    mat[2 * i + 1].w = pdf_area;
+}
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
+void PT_LAUNCH(launch_scene_setup)(float4* shape, float4* mat, uint32_t n, hipStream_t st) {
+    if (n == 0u) return;
+    hipLaunchKernelGGL(k_scene_setup, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, shape, mat, n);
+}
 void PT_LAUNCH(launch_debug_fn)(const DebugFnArgs& a, hipStream_t st) {
     if (a.n == 0u) return;
     hipLaunchKernelGGL(k_debug_fn, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);

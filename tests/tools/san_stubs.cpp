@@ -4,6 +4,8 @@
 
 #include "../../pathtrace_amd/csrc/pt_kernels.h"
 namespace ptk {
+void launch_scene_setup_exact(float4*, float4*, uint32_t, hipStream_t) { std::abort(); }
+void launch_scene_setup_fast(float4*, float4*, uint32_t, hipStream_t) { std::abort(); }
 void launch_paths_exact(const BounceArgs&, uint32_t, hipStream_t) { std::abort(); }
 void launch_paths_fast(const BounceArgs&, uint32_t, hipStream_t) { std::abort(); }
 void launch_resolve(const ResolveArgs&, hipStream_t) { std::abort(); }
