@@ -64,7 +64,10 @@ PT_DEV f3 cross(f3 a, f3 b) {                                                   
     return mk(msub(a.y, b.z, a.z, b.y), msub(a.z, b.x, a.x, b.z), msub(a.x, b.y, a.y, b.x));
 }
 PT_DEV float length(f3 a) { return pt_sqrt(dot(a, a)); }                     // math.rs:38
-#if PT_MATH_EXACT || !defined(PT_RSQ_NORMALIZE)
+#ifndef PT_RSQ_NORMALIZE
+#define PT_RSQ_NORMALIZE 1     // fast arithmetic normalises with one v_rsq_f32 (round 3; same-box A/B on C2: 6.19 -> 6.10 ms per step)
+#endif
+#if PT_MATH_EXACT || !PT_RSQ_NORMALIZE
 PT_DEV f3 normalize(f3 a) { float len = length(a); return len > 0.0f ? a / len : a; }   // math.rs:48-51
 // to_light.length() and to_light.normalize() of the same vector (rendering.rs:59-60, shape.rs:218-221)
 PT_DEV f3 normalize_len(f3 a, float& len) { len = length(a); return len > 0.0f ? a / len : a; }
@@ -292,7 +295,7 @@ PT_DEV void triangle_sample(f3 v0, f3 e1, f3 e2, f3 normal, float pdf_area, f3 f
         point = madd(e2, v, madd(e1, u, v0));
     }
     f3 to_light = point - from;
-#if PT_MATH_EXACT || !defined(PT_RSQ_NORMALIZE)
+#if PT_MATH_EXACT || !PT_RSQ_NORMALIZE
     float d = length(to_light);
     f3 light_dir = to_light / d;                     // shape.rs:218-221
 #else
