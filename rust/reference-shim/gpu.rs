@@ -8,7 +8,7 @@
 //! (`src/main.rs:1`): every `unsafe` block of the integration is inside the `pathtrace-amd` wrapper crate.
 //!
 //! Same per-pixel seeding convention as `main.rs:51` (the RNG key of pixel (x, y) is the pair (x, y)); the
-//! generator is the library's counter-based Philox4x32-10, not rand's ChaCha12, so a GPU film and a CPU film
+//! generator is the library's counter-based Philox4x32 (7 rounds), not rand's ChaCha12, so a GPU film and a CPU film
 //! are two draws of the same estimator, not the same numbers.
 use crate::math::Vector3;
 use crate::world::{Color, World, HEIGHT, SAMPLE_NUM, WIDTH};
