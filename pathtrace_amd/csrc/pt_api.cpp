@@ -505,6 +505,7 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
         uint32_t n_mirror = 0;
         for (uint32_t i = 0; i < n; ++i) n_mirror += objs[i].mat_tag == PT_MAT_MIRROR;
         c->split_ok = n_mirror != 0 && 2 * n_mirror <= n;
+        c->view.no_mirror = n_mirror == 0 ? 1u : 0u;
         c->view.no_oren_nayar = 1u;
         for (uint32_t i = 0; i < n; ++i)
             if (objs[i].mat_tag == PT_MAT_OREN_NAYAR) c->view.no_oren_nayar = 0u;
@@ -568,7 +569,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // level0_form 3 / default for scenes with a minority of Mirror objects: the regenerating form with the Mirror vertices batched
     const bool lds_job = !list && !prm->accel && c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
     const bool split = lds_job && (c->tuning.level0_form == 3 || (c->tuning.level0_form == 0 && c->split_ok && kSplitByDefault));
-    const bool regen_scene = split || ((c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && c->view.diffuse_only)) && lds_job);
+    // default: diffuse scenes and (round 3) scenes whose only non-diffuse surfaces are OrenNayar -- anything without the GGX code
+    const bool regen_scene = split || ((c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && (c->view.diffuse_only || c->view.no_mirror))) && lds_job);
     uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : (regen_scene ? kDefaultMaxPathsRegen : kDefaultMaxPaths);
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)

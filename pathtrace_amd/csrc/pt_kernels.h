@@ -45,6 +45,7 @@ struct SceneView {
     uint32_t scan_f4;        // float4 count of `scan`
     uint32_t n_runs, n_objs, n_lights;
     uint32_t diffuse_only;   // every material is Lambertian or emissive: kernels without the GGX / OrenNayar code
+    uint32_t no_mirror;      // no Mirror surface (k_paths_regen without the GGX code also for scenes with OrenNayar surfaces)
     uint32_t no_oren_nayar;  // no OrenNayar surface (k_paths_regen_split: its plain iterations are then the diffuse-only code)
     BvhView bvh;             // valid only for launches with accel != 0
 };

@@ -815,8 +815,10 @@ k_paths(BounceArgs a) {
 // Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 79 VGPRs
 // (6 waves per SIMD), the generic one 93 (5; reached only with PtTuning.level0_form = 2).
 constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
-template <bool MIS, bool DIFFUSE>
-__global__ void __launch_bounds__(kBlock, DIFFUSE ? kRegenWavesDiffuse : kRegenWavesGeneric) k_paths_regen(BounceArgs a) {
+// DIFFUSE = the material set the kernel is compiled for (kMatsDiffuse / kMatsNoMirror / kMatsAll); round 3 added the
+// middle one: a scene with OrenNayar but no Mirror surface (material.rs:166-296) takes this kernel too by default.
+template <bool MIS, int DIFFUSE>
+__global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesDiffuse : kRegenWavesGeneric) k_paths_regen(BounceArgs a) {
     extern __shared__ float4 lds[];
     __shared__ float4 s_pool_d[kBlock / 64][kPool];      // (d.x, d.y, d.z, bits(tile_row << 16 | x))
     __shared__ uint32_t s_pool_s[kBlock / 64][kPool];    // s_local << 16 (depth 0)
@@ -1603,8 +1605,9 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
             else { if (mis) hipLaunchKernelGGL((k_paths_regen_split<true, kMatsNoMirror>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen_split<false, kMatsNoMirror>), g, b, lds, st, a); }
             return;
         }
-        if (diffuse) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, true>), g, b, lds, st, a); }
-        else { if (mis) hipLaunchKernelGGL((k_paths_regen<true, false>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, false>), g, b, lds, st, a); }
+        if (diffuse) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, kMatsDiffuse>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, kMatsDiffuse>), g, b, lds, st, a); }
+        else if (a.sc.no_mirror) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, kMatsNoMirror>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, kMatsNoMirror>), g, b, lds, st, a); }
+        else { if (mis) hipLaunchKernelGGL((k_paths_regen<true, kMatsAll>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, kMatsAll>), g, b, lds, st, a); }
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }

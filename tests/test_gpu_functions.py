@@ -321,7 +321,18 @@ def test_tuning_knobs_do_not_change_the_film(pt, gpu_ctx):
         gpu_ctx.set_tuning()
 
 
-@pytest.mark.parametrize("scene,exact", [(2, 0), (2, 1), (1, 0), (1, 1)])
+def _oren_nayar_cornell(pt):
+    """C2 with every Lambertian surface OrenNayar (material.rs:166-296), rough and smooth: a scene without Mirror
+    surfaces, which takes the regenerating kernel compiled without the GGX code by default (round 3)."""
+    objs = list(pt.builtin_scene(2))
+    for k, o in enumerate(objs):
+        if o.mat_tag == 0:
+            o.mat_tag = 3
+            o.mat[3] = [0.0, 0.3, 0.6, 1.0][k % 4]
+    return (pt._lib.PtObject * len(objs))(*objs)
+
+
+@pytest.mark.parametrize("scene,exact", [(2, 0), (2, 1), (1, 0), (1, 1), ("oren_nayar", 0), ("oren_nayar", 1)])
 def test_level0_forms_give_the_same_film(pt, gpu_ctx, scene, exact):
     """The level-0 launch of a large batch has two forms: the queue form (k_paths: state through HBM once per vertex,
     in-place compaction) and the regenerating form (k_paths_regen: a path stays in its lane's registers, a lane whose path
@@ -330,7 +341,7 @@ def test_level0_forms_give_the_same_film(pt, gpu_ctx, scene, exact):
     the deepest vertex are identical, for the diffuse scene (regeneration is the default there) and for the reference
     scene with its glass sphere, in both arithmetic modes, for several grid sizes of the regenerating launch (1
     workgroup; fewer and more than the device holds at once)."""
-    gpu_ctx.upload(pt.builtin_scene(scene))
+    gpu_ctx.upload(_oren_nayar_cornell(pt) if scene == "oren_nayar" else pt.builtin_scene(scene))
     cam = pt.camera_new(width=1024, height=640)
     prm = pt.default_params(spp=8, exact_math=exact)                  # 5.2 M paths: above the hand-off threshold
     try:
@@ -346,6 +357,8 @@ def test_level0_forms_give_the_same_film(pt, gpu_ctx, scene, exact):
             st = gpu_ctx.stats()
             assert torch_equal(lin, ref) and torch_equal(rgba, ref8), (form, wgs)
             assert (st.vertices, st.shadow_rays, st.max_depth_reached) == (base.vertices, base.shadow_rays, base.max_depth_reached)
+            if form == 0:     # the default is a regenerating form for all three scenes: one launch, no continuation launch
+                assert st.bounce_launches == 1
     finally:
         gpu_ctx.set_tuning()
 
