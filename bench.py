@@ -337,14 +337,13 @@ def main(argv=None):
         if args.accel == 1 or (args.accel == 2 and len(objs) > 512):
             kernel = "k_paths_bvh<MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
         elif len(objs) <= 128:
-            # large batches over a scene in LDS: the regenerating form where the library takes it (pt_api.cpp: diffuse scenes
-            # by default, PtTuning.level0_form), the queue form otherwise
+            # large batches over a scene in LDS: a regenerating form by default (pt_api.cpp; PtTuning.level0_form = 1: the queue form)
             big = acc["samples"] / n_stat / max(p_launches, 1) > (1 << 22)
             n_mirror = sum(1 for o in objs if o.mat_tag == 2)
             if big and (args.level0_form == 3 or (args.level0_form == 0 and not diffuse and 0 < 2 * n_mirror <= len(objs))):
                 kernel = "k_paths_regen_split<MIS> (regenerating form, the Mirror vertices of a wave shaded in batches of 64)"
-            elif big and (args.level0_form == 2 or (args.level0_form == 0 and diffuse)):
-                kernel = "k_paths_regen<MIS, %s>" % ("DIFFUSE" if diffuse else "generic")
+            elif big and args.level0_form in (0, 2):
+                kernel = "k_paths_regen<MIS, %s>" % ("DIFFUSE" if diffuse else "no Mirror code" if n_mirror == 0 else "every material")
             else:
                 kernel = "k_paths<kModeLds, MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
         else:

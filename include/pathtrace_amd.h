@@ -130,11 +130,10 @@ typedef struct {
     uint32_t bvh_leaf;       /* accel = 1: leaf primitives are tested when this many lanes wait at a leaf (20)       */
     uint32_t cont_workgroups;/* workgroups of the continuation launch that finishes the handed-over tails             */
     uint32_t level0_form;    /* level-0 launch of a large batch over a scene in LDS.  0: paths stay in registers and a
-                                lane whose path ends takes the batch's next one (k_paths_regen) if no material is Mirror
-                                (Lambertian / emissive / OrenNayar); the same with the Mirror vertices of a wave set aside and shaded
-                                64 at a time (k_paths_regen_split) if at most half of the objects are Mirror (the
-                                reference's own scene); the queue form otherwise.  1: the queue form; 2: k_paths_regen;
-                                3: k_paths_regen_split                                                                */
+                                lane whose path ends takes the batch's next one (k_paths_regen, compiled for the scene's
+                                material set); with the Mirror vertices of a wave set aside and shaded 64 at a time
+                                (k_paths_regen_split) if some but at most half of the objects are Mirror (the
+                                reference's own scene).  1: the queue form; 2: k_paths_regen; 3: k_paths_regen_split  */
     uint32_t regen_workgroups;/* workgroups of that regenerating launch (0: what the device holds at once)             */
 } PtTuning;
 

@@ -569,8 +569,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // level0_form 3 / default for scenes with a minority of Mirror objects: the regenerating form with the Mirror vertices batched
     const bool lds_job = !list && !prm->accel && c->view.n_objs <= ptk::kSmallObjs && c->view.blob_f4 != 0;
     const bool split = lds_job && (c->tuning.level0_form == 3 || (c->tuning.level0_form == 0 && c->split_ok && kSplitByDefault));
-    // default: diffuse scenes and (round 3) scenes whose only non-diffuse surfaces are OrenNayar -- anything without the GGX code
-    const bool regen_scene = split || ((c->tuning.level0_form == 2 || (c->tuning.level0_form == 0 && (c->view.diffuse_only || c->view.no_mirror))) && lds_job);
+    // default (round 3): every scene in LDS takes a regenerating form -- compiled for its material set (diffuse only; no
+    // Mirror; everything); with the Mirror vertices batched where they are the exception (split, above).  The queue form
+    // is level0_form = 1 (all-Mirror Cornell scene: queue form 12.6 ms, regenerating 10.0, split 13.8; tools/r03/mirror_forms.py)
+    const bool regen_scene = split || ((c->tuning.level0_form == 2 || c->tuning.level0_form == 0) && lds_job);
     uint64_t cap = prm->max_paths_in_flight ? prm->max_paths_in_flight : (regen_scene ? kDefaultMaxPathsRegen : kDefaultMaxPaths);
     if (cap > (1ull << 30)) cap = 1ull << 30;
     if (np64 > cap)

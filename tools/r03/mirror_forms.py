@@ -1,0 +1,34 @@
+"""ms per 1024^2 x 64 render of a Cornell scene whose diffuse surfaces are all Mirror (GGX: rough metal walls, glass and
+metal spheres), queue form vs the regenerating forms: python tools/r03/mirror_forms.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import pathtrace_amd as pt
+dev = torch.device("cuda", 0)
+objs = list(pt.builtin_scene(2))
+for k, o in enumerate(objs):
+    if o.mat_tag == 0:
+        col = [o.mat[0], o.mat[1], o.mat[2]]
+        o.mat_tag = 2                      # Mirror: roughness, colour, metallic, ior
+        o.mat[0] = [0.3, 0.5, 0.7, 0.9][k % 4]
+        o.mat[1], o.mat[2], o.mat[3] = col
+        o.mat[4] = 0.0 if k in (6, 8) else 1.0
+        o.mat[5] = 1.5
+objs = (pt._lib.PtObject * len(objs))(*objs)
+cam = pt.camera_new(width=1024, height=1024); prm = pt.default_params(spp=64)
+lin = torch.empty((1024, 1024, 3), dtype=torch.float32, device=dev); rgba = torch.empty((1024, 1024, 4), dtype=torch.uint8, device=dev)
+ref = None
+for form in (1, 2, 3, 0):
+    ctx = pt.Context(0); ctx.upload(objs); ctx.set_tuning(level0_form=form)
+    st = torch.cuda.Stream(dev); ctx.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        for _ in range(2): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(6): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
+        e1.record(st); st.synchronize()
+    ctx.sync(); s = ctx.stats()
+    same = "" if ref is None else f", film == queue form: {bool(torch.equal(lin, ref))}"
+    if ref is None: ref = lin.clone()
+    print(f"all-Mirror Cornell, level0_form {form}: {e0.elapsed_time(e1) / 6:.3f} ms per render, {s.vertices / 1e6:.0f} M vertices, {s.bounce_launches} path launches{same}", flush=True)
+    ctx.set_stream(None); ctx.close()
