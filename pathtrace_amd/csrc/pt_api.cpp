@@ -94,6 +94,11 @@ constexpr uint32_t kExportSmall = 64;          // a wave hands its segment over 
 #define PT_EXPORT_MIN_LOG2 22
 #endif
 constexpr uint32_t kExportMinPaths = 1u << PT_EXPORT_MIN_LOG2;
+// batches of more paths than this take the regenerating level-0 kernel (where the scene allows it)
+#ifndef PT_REGEN_MIN_LOG2
+#define PT_REGEN_MIN_LOG2 17
+#endif
+constexpr uint32_t kRegenMinPaths = 1u << PT_REGEN_MIN_LOG2;
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
 // PT_ACCEL_AUTO: the BVH when the scene is larger than one LDS blob and spheres + 2.5 x triangles > 512 (C4-like
 // scenes: the tiled scan costs ~0.11 ms per sphere and 67 M samples -- a Moeller-Trumbore test 2.5x that --, the BVH
@@ -602,7 +607,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const uint32_t seg_cap = ((chunks_max + nw - 1) / nw) * 64u;
     // Tail hand-off: the level-0 launch of a large batch exports what its waves have left below one chunk; ONE
     // continuation launch of fixed size takes that queue up.  It reads the count on the device.
-    const bool hand_off = !inject && n_paths_max > kExportMinPaths;
+    // (scenes that take a regenerating level-0 kernel have their own threshold: that launch needs no continuation launch)
+    const bool hand_off = !inject && n_paths_max > (regen_scene ? kRegenMinPaths : kExportMinPaths);
     // Such a batch over a scene in LDS takes the regenerating level-0 kernel: paths live in registers, a lane whose
     // path ends takes the next one of the batch; grid = the waves the device holds at once (k_paths_regen).
     // (Scenes with GGX / OrenNayar surfaces keep the queue form unless asked: paths of every depth and material share a
