@@ -251,22 +251,29 @@ def main(argv=None):
     # the last one is completed inside the timed region.  (Single-process form: the gather is inside render_into.)
     film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev, always_collective=True) if dist_path else None
 
-    def step(record):
+    # One process per GPU over RCCL: the steps are enqueued back to back -- render, pack and gather are ordered by the stream,
+    # nothing in a step needs the host (a rank's share of the job is ~1 ms at 8 GPUs; a host round trip per step would be
+    # several percent of it).  The counters and launch times are then read once, after the last step, and stand for every
+    # step (each step renders the same samples).  Every other mode synchronises and reads them per step.
+    async_steps = dist_path and args.backend == "nccl"
+
+    def step(record, weight=1):
         ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
-        ctx.sync()
+        if not async_steps or record:
+            ctx.sync()
         if dist_path:
             film_gather.start(lin.to(comm_dev), rgba.to(comm_dev))
         if record:
             st = ctx.stats()
-            acc["vertices"] += st.vertices
-            acc["shadow_rays"] += st.shadow_rays
-            acc["samples"] += st.samples
-            acc["bounce_ms"] += st.bounce_kernel_ms
-            acc["launches"] += st.bounce_launches
-            acc["total_ms"] += st.total_ms
-            acc["p_vertices"] += st.primary_vertices
-            acc["p_ms"] += st.primary_kernel_ms
-            acc["p_launches"] += st.primary_launches
+            acc["vertices"] += st.vertices * weight
+            acc["shadow_rays"] += st.shadow_rays * weight
+            acc["samples"] += st.samples * weight
+            acc["bounce_ms"] += st.bounce_kernel_ms * weight
+            acc["launches"] += st.bounce_launches * weight
+            acc["total_ms"] += st.total_ms * weight
+            acc["p_vertices"] += st.primary_vertices * weight
+            acc["p_ms"] += st.primary_kernel_ms * weight
+            acc["p_launches"] += st.primary_launches * weight
 
     def barrier():
         if dist_path:
@@ -284,8 +291,11 @@ def main(argv=None):
     barrier()
     device_sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        if async_steps:
+            step(k + 1 == args.steps, weight=args.steps)
+        else:
+            step(True)
     if dist_path:
         frame, frame8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
     device_sync()
