@@ -363,18 +363,20 @@ def test_level0_forms_give_the_same_film(pt, gpu_ctx, scene, exact):
         gpu_ctx.set_tuning()
 
 
-def test_regenerating_form_with_ragged_batches_and_bands(pt, gpu_ctx):
-    """Batches whose path count is not a multiple of 64, several of them (tails overlapped on the side stream), and a
-    row band: the regenerating form equals the queue form."""
-    gpu_ctx.upload(pt.builtin_scene(2))
+@pytest.mark.parametrize("scene,form", [(2, 2), (1, 3), (1, 2)])
+def test_regenerating_form_with_ragged_batches_and_bands(pt, gpu_ctx, scene, form):
+    """Batches whose path count is not a multiple of 64, several of them, a row band, a sample offset: the regenerating
+    forms (2: k_paths_regen; 3: k_paths_regen_split, the reference scene's default) equal the queue form."""
+    gpu_ctx.upload(pt.builtin_scene(scene))
     cam = pt.camera_new(width=1023, height=517)
-    for kw in (dict(spp=19, max_paths_in_flight=1023 * 517 * 9), dict(spp=20, band_rows=100, band_index=1, band_count=2)):
+    for kw in (dict(spp=19, max_paths_in_flight=1023 * 517 * 9), dict(spp=20, band_rows=100, band_index=1, band_count=2),
+               dict(spp=7, spp_offset=1000003, max_paths_in_flight=1023 * 517 * 3)):
         prm = pt.default_params(**kw)
         try:
             gpu_ctx.set_tuning(level0_form=1)
             ref, ref8 = gpu_ctx.render(cam, prm)
             base = gpu_ctx.stats()
-            gpu_ctx.set_tuning(level0_form=2)
+            gpu_ctx.set_tuning(level0_form=form)
             lin, rgba = gpu_ctx.render(cam, prm)
             st = gpu_ctx.stats()
         finally:
