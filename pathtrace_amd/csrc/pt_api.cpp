@@ -614,8 +614,19 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // (Scenes with GGX / OrenNayar surfaces keep the queue form unless asked: paths of every depth and material share a
     // wave there, and the divergence costs what the form saves -- C1 12.40 vs 12.21 ms.)
     const bool regen = regen_scene && hand_off;
+    // its grid = the workgroups the device holds at once: the kernel's occupancy with THIS scene's LDS blob (a 128-object
+    // scene leaves room for fewer workgroups per CU than the compile-time figure)
+    uint32_t regen_per_cu = split ? ptk::kRegenWavesSplit : c->view.diffuse_only ? ptk::kRegenWavesDiffuse : ptk::kRegenWavesGeneric;
+    if (regen_scene) {
+        ptk::BounceArgs q{};
+        q.sc = view_for(c, prm->exact_math);
+        q.integrator = prm->integrator;
+        q.xchg = split ? reinterpret_cast<float4*>(1) : nullptr;       // selects the kernel only
+        const uint32_t occ = prm->exact_math ? ptk::regen_blocks_per_cu_exact(q) : ptk::regen_blocks_per_cu_fast(q);
+        if (occ != 0u) regen_per_cu = std::min(regen_per_cu, occ);
+    }
     const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups :
-                                c->n_cus * (split ? ptk::kRegenWavesSplit : c->view.diffuse_only ? ptk::kRegenWavesDiffuse : ptk::kRegenWavesGeneric));
+                                c->n_cus * regen_per_cu);
     const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
     const uint32_t nw_cont = cont_grid * kWavesPerBlock;
     // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup

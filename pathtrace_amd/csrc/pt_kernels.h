@@ -157,6 +157,9 @@ constexpr uint32_t kRegenCounters = 8, kRegenCounterStride = 64;
 // mode on that mode's copy of the records
 void launch_scene_setup_exact(float4* shape, float4* mat, uint32_t n_objs, hipStream_t st);
 void launch_scene_setup_fast(float4* shape, float4* mat, uint32_t n_objs, hipStream_t st);
+// workgroups per CU of the regenerating level-0 kernel `a` selects (sc, integrator, xchg), with the scene's LDS blob; 0 = unknown
+uint32_t regen_blocks_per_cu_exact(const BounceArgs& a);
+uint32_t regen_blocks_per_cu_fast(const BounceArgs& a);
 void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);
 void launch_paths_fast(const BounceArgs& a, uint32_t grid, hipStream_t st);
 

@@ -1587,6 +1587,28 @@ static void launch_paths_bvh(const BounceArgs& a, uint32_t grid, size_t lds, hip
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
+// the regenerating level-0 kernel a launch takes: compiled for the scene's material set; with the Mirror vertices batched
+// (k_paths_regen_split) when the host passes exchange memory
+typedef void (*RegenKernel)(BounceArgs);
+static RegenKernel regen_kernel(const BounceArgs& a) {
+    const bool mis = a.integrator == 0;
+    if (a.xchg) {
+        if (a.sc.no_oren_nayar) return mis ? k_paths_regen_split<true, kMatsDiffuse> : k_paths_regen_split<false, kMatsDiffuse>;
+        return mis ? k_paths_regen_split<true, kMatsNoMirror> : k_paths_regen_split<false, kMatsNoMirror>;
+    }
+    if (a.sc.diffuse_only) return mis ? k_paths_regen<true, kMatsDiffuse> : k_paths_regen<false, kMatsDiffuse>;
+    if (a.sc.no_mirror) return mis ? k_paths_regen<true, kMatsNoMirror> : k_paths_regen<false, kMatsNoMirror>;
+    return mis ? k_paths_regen<true, kMatsAll> : k_paths_regen<false, kMatsAll>;
+}
+// Workgroups of that kernel one CU holds at once, given the scene's LDS blob (0 if the query fails: the caller falls back
+// to the compile-time occupancy).  The launch must not be larger than what is resident: the statically dealt quarter of
+// the chunks of a wave that starts late is a serial tail.
+uint32_t PT_LAUNCH(regen_blocks_per_cu)(const BounceArgs& a) {
+    int n = 0;
+    const size_t lds = scene_lds_bytes(a.sc, kModeLds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_kernel(a), (int)kBlock, lds) != hipSuccess || n < 0) return 0u;
+    return (uint32_t)n;
+}
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
     const int mode = scene_mode(a.sc, a.accel);
     const size_t lds = scene_lds_bytes(a.sc, mode);
@@ -1597,17 +1619,8 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
         else launch_paths_bvh<false, true>(a, grid, lds, st);
         return;
     }
-    if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen)
-        const bool mis = a.integrator == 0;
-        const dim3 g(grid), b(kBlock);
-        if (a.xchg) {                              // ... with the Mirror vertices batched (k_paths_regen_split)
-            if (a.sc.no_oren_nayar) { if (mis) hipLaunchKernelGGL((k_paths_regen_split<true, kMatsDiffuse>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen_split<false, kMatsDiffuse>), g, b, lds, st, a); }
-            else { if (mis) hipLaunchKernelGGL((k_paths_regen_split<true, kMatsNoMirror>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen_split<false, kMatsNoMirror>), g, b, lds, st, a); }
-            return;
-        }
-        if (diffuse) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, kMatsDiffuse>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, kMatsDiffuse>), g, b, lds, st, a); }
-        else if (a.sc.no_mirror) { if (mis) hipLaunchKernelGGL((k_paths_regen<true, kMatsNoMirror>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, kMatsNoMirror>), g, b, lds, st, a); }
-        else { if (mis) hipLaunchKernelGGL((k_paths_regen<true, kMatsAll>), g, b, lds, st, a); else hipLaunchKernelGGL((k_paths_regen<false, kMatsAll>), g, b, lds, st, a); }
+    if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen*)
+        hipLaunchKernelGGL(regen_kernel(a), dim3(grid), dim3(kBlock), lds, st, a);
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }

@@ -6,6 +6,8 @@
 namespace ptk {
 void launch_scene_setup_exact(float4*, float4*, uint32_t, hipStream_t) { std::abort(); }
 void launch_scene_setup_fast(float4*, float4*, uint32_t, hipStream_t) { std::abort(); }
+uint32_t regen_blocks_per_cu_exact(const BounceArgs&) { return 0; }
+uint32_t regen_blocks_per_cu_fast(const BounceArgs&) { return 0; }
 void launch_paths_exact(const BounceArgs&, uint32_t, hipStream_t) { std::abort(); }
 void launch_paths_fast(const BounceArgs&, uint32_t, hipStream_t) { std::abort(); }
 void launch_resolve(const ResolveArgs&, hipStream_t) { std::abort(); }
