@@ -16,8 +16,13 @@
 //                             linear scan, out of LDS (MODE = kModeLds, scenes <= 128 objects) or streamed through
 //                             an LDS tile (kModeTiled).  Pass 0 generates the camera rays (camera.rs:139-147,
 //                             world.rs:299) or, in a continuation launch (OVF), takes over the overflow queue.
-//   k_paths_bvh<MIS, OVF>     the same for PtRenderParams.accel = 1: hit_scene by BVH traversal, each pass cut into
-//                             extend / connect / occlude / shade stages with per-lane ray refill.
+//   k_paths_regen<MIS, MATS>  level-0 launch of a batch of > 2^17 paths over a scene in LDS: a path stays in its lane's registers,
+//                             a lane whose path ends takes the batch's next one (chunk counters); compiled per material set.
+//   k_paths_regen_split<..>   the same for scenes with a few Mirror objects (the reference's own): a wave's Mirror vertices are
+//                             set aside on a per-wave stack and shaded 64 at a time.
+//   k_paths_bvh<MIS, OVF>     the queue form for PtRenderParams.accel = 1: hit_scene by traversal of a 4-wide BVH, each pass cut
+//                             into extend / connect / occlude / shade stages with per-lane ray refill.
+//   k_scene_setup             per-object constants (a triangle's unit normal and 1 / area) at pt_scene_upload.
 //   k_resolve                 film: per-pixel f64 sum in sample order, mean, gamma, RGBA8 (world.rs:311-332).
 //   k_debug_hit[_bvh]         hit_scene on arbitrary rays (parity tests).
 //
