@@ -361,41 +361,36 @@ PT_DEV float ggx_d(float alpha2, float n_h) {                              // mi
     float denom = (n_h * n_h) * (alpha2 - 1.0f) + 1.0f;
     return pt_div(alpha2, kPi * denom * denom);
 }
-// Mirror::brdf, mirror.rs:62-88
-PT_DEV void mirror_brdf(const Mat& m, f3 dir_in, f3 o, f3 n, f3& f, float& pdf) {
+// Mirror::brdf (mirror.rs:62-88) and Mirror::btdf (:90-124) in one body: a wave that shades GGX vertices usually has
+// reflecting and transmitting lanes side by side, and as two functions behind a divergent branch the parts they share --
+// the half vector's normalisation, D, G, F: 55 of ~85 instructions each -- ran twice.  Every lane still evaluates its own
+// case's expressions in the reference's order (i * 1 is i exactly, so `i * (1 | eta) + o` is `i + o` or `i * eta + o`).
+PT_DEV void mirror_eval(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, bool is_refl, f3& f, float& pdf) {
     f3 i = -dir_in;
     float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
-    f3 h = normalize(i + o);
+    f3 h = normalize(i * (is_refl ? 1.0f : eta) + o);                          // :64 / :97
+    if (!is_refl) h = -h;
     float n_h = dot(n, h);
     float d = ggx_d(alpha2, n_h);
-    float i_n = __builtin_fmaxf(dot(n, i), 0.0f);
-    float o_n = __builtin_fmaxf(dot(n, o), 0.0f);
+    float ni = dot(n, i), no = dot(n, o);
+    float i_n = is_refl ? __builtin_fmaxf(ni, 0.0f) : __builtin_fabsf(ni);      // :71-72 / :104-105
+    float o_n = is_refl ? __builtin_fmaxf(no, 0.0f) : __builtin_fabsf(no);
     float g = mirror_g(m, i_n, o_n);
-    float cos_theta = __builtin_fmaxf(dot(i, h), 0.0f);
+    float i_h = dot(i, h);
+    float cos_theta = is_refl ? __builtin_fmaxf(i_h, 0.0f) : __builtin_fabsf(i_h);
     f3 fr = mirror_f(m, cos_theta);
-    float denom_brdf = 4.0f * i_n * o_n;
-    f = d * g * fr / denom_brdf;
-    float i_h = __builtin_fabsf(dot(i, h));
-    pdf = pt_div(d * __builtin_fabsf(n_h), 4.0f * i_h);
-}
-// Mirror::btdf, mirror.rs:90-124
-PT_DEV void mirror_btdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, float& pdf) {
-    f3 i = -dir_in;
-    f3 h = -(normalize(i * eta + o));
-    float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
-    float n_h = dot(n, h);
-    float d = ggx_d(alpha2, n_h);
-    float i_n = __builtin_fabsf(dot(n, i));
-    float o_n = __builtin_fabsf(dot(n, o));
-    float g = mirror_g(m, i_n, o_n);
-    float i_h = dot(i, h), o_h = dot(o, h);
-    float cos_theta = __builtin_fabsf(i_h);
-    float denom_term = eta * i_h + o_h;
-    f3 fr = mirror_f(m, cos_theta);
-    f = (mk(1.0f, 1.0f, 1.0f) - fr) * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
-        (i_n * o_n * denom_term * denom_term);
-    float jac = pt_div(__builtin_fabsf(o_h), denom_term * denom_term);
-    pdf = d * __builtin_fabsf(n_h) * jac;
+    if (is_refl) {
+        float denom_brdf = 4.0f * i_n * o_n;
+        f = d * g * fr / denom_brdf;
+        pdf = pt_div(d * __builtin_fabsf(n_h), 4.0f * __builtin_fabsf(i_h));
+    } else {
+        float o_h = dot(o, h);
+        float denom_term = eta * i_h + o_h;
+        f = (mk(1.0f, 1.0f, 1.0f) - fr) * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
+            (i_n * o_n * denom_term * denom_term);
+        float jac = pt_div(__builtin_fabsf(o_h), denom_term * denom_term);
+        pdf = d * __builtin_fabsf(n_h) * jac;
+    }
 }
 // Mirror::sample_ggx_vndf, mirror.rs:17-60
 PT_DEV f3 mirror_vndf(const Mat& m, f3 view, f3 n, float r1, float r2) {
@@ -438,38 +433,33 @@ PT_DEV void mirror_sample(const Mat& m, f3 dir_in, float eta, f3 n, float r1, fl
     float alpha = m.roughness * m.roughness, alpha2 = alpha * alpha;
     float n_h = dot(n, h);
     float d = ggx_d(alpha2, n_h);
+    // Both lobes in one body (as mirror_eval): the outgoing direction's normalisation, G, G1 and the VNDF pdf are common.
+    // cos_t is only read by transmitting lanes (total internal reflection reflects: rr_f = 1).
+    float cos_t = pt_sqrt(cos2_t);
+    f3 o = is_reflect ? 2.0f * i_h * h - i : h * (eta * i_h - cos_t) - i * eta;      // :240 / :270
+    f3 on = normalize(o);
+    float n_on = dot(n, on);
+    float o_n = is_reflect ? __builtin_fmaxf(n_on, 0.0f) : __builtin_fabsf(n_on);
+    float i_n = is_reflect ? __builtin_fmaxf(i_dot_n, 0.0f) : __builtin_fabsf(i_dot_n);
+    float g = mirror_g(m, i_n, o_n);
+    float g1v = mirror_g1(m, i_n);
+    float pdf_vndf = pt_div(g1v * d * __builtin_fmaxf(i_h, 0.0f), i_n);
+    f3 val; float p;
     if (is_reflect) {
-        f3 o = 2.0f * i_h * h - i;
-        f3 on = normalize(o);
-        float o_n = __builtin_fmaxf(dot(n, on), 0.0f);
-        float i_n = __builtin_fmaxf(i_dot_n, 0.0f);
-        float g = mirror_g(m, i_n, o_n);
         float denom_brdf = 4.0f * i_n * o_n;
-        f3 brdf = fr * d * g / (denom_brdf * rr_f);
-        float g1v = mirror_g1(m, i_n);
-        float pdf_vndf = pt_div(g1v * d * __builtin_fmaxf(i_h, 0.0f), i_n);
-        float p = pt_div(pdf_vndf, 4.0f * __builtin_fabsf(i_h));
-        if (!finite3(brdf) || !__builtin_isfinite(p) || p <= 0.0f) return;
-        wo = on; f = brdf; pdf = p; cos_out = o_n;
+        val = fr * d * g / (denom_brdf * rr_f);
+        p = pt_div(pdf_vndf, 4.0f * __builtin_fabsf(i_h));
     } else {
-        float cos_t = pt_sqrt(cos2_t);
-        f3 o = h * (eta * i_h - cos_t) - i * eta;
-        f3 on = normalize(o);
         float o_h = dot(on, h);
-        float o_n = __builtin_fabsf(dot(n, on));
-        float i_n = __builtin_fabsf(i_dot_n);
         float denom_term = eta * i_h + o_h;
-        float g = mirror_g(m, i_n, o_n);
         f3 one_f = mk(1.0f, 1.0f, 1.0f) - fr;
-        f3 btdf = one_f * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
-                  (i_n * o_n * denom_term * denom_term * (1.0f - rr_f));
+        val = one_f * d * g * __builtin_fabsf(i_h) * __builtin_fabsf(o_h) /
+              (i_n * o_n * denom_term * denom_term * (1.0f - rr_f));
         float jac = pt_div(__builtin_fabsf(o_h), denom_term * denom_term);
-        float g1v = mirror_g1(m, i_n);
-        float pdf_vndf = pt_div(g1v * d * __builtin_fmaxf(i_h, 0.0f), i_n);
-        float p = pdf_vndf * jac;
-        if (!finite3(btdf) || !__builtin_isfinite(p) || p <= 0.0f) return;
-        wo = on; f = btdf; pdf = p; cos_out = o_n;
+        p = pdf_vndf * jac;
     }
+    if (!finite3(val) || !__builtin_isfinite(p) || p <= 0.0f) return;
+    wo = on; f = val; pdf = p; cos_out = o_n;
 }
 // OrenNayar::bsdf_pdf, material.rs:221-265.  The reference takes cos(phi_i - phi_o) of two atan2 azimuths
 // (:246-249); the f32 specification uses the same number without trigonometry: the cosine of the angle between
@@ -509,8 +499,7 @@ PT_DEV void bsdf_pdf(const Mat& m, f3 dir_in, float eta, f3 o, f3 n, f3& f, floa
         float i_n = dot(i, n), o_n = dot(o, n);
         bool is_refl = i_n * o_n > 0.0f;
         if (m.metallic > 0.99f && !is_refl) { f = mk(0.0f, 0.0f, 0.0f); pdf = 1.0f; }
-        else if (is_refl) mirror_brdf(m, dir_in, o, n, f, pdf);
-        else mirror_btdf(m, dir_in, eta, o, n, f, pdf);
+        else mirror_eval(m, dir_in, eta, o, n, is_refl, f, pdf);
     } else {
         oren_nayar_eval(m, dir_in, o, n, f, pdf);
     }
