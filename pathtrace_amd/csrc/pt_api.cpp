@@ -649,7 +649,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (prm->accel && ((rc = c->bvh_aux.ensure(q_slots)) || (rc = c->bvh_sray[0].ensure(q_slots)) ||
                        (rc = c->bvh_sray[1].ensure(q_slots))))
         return rc;
-    if (regen && split && (rc = c->xchg.ensure((size_t)regen_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave))) return rc;
+    if (regen && split && (rc = c->xchg.ensure((size_t)regen_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024)))   // + slack: a violated stack
+        return rc;                                                                                                         // invariant (reported) stays inside the buffer
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
     if (overlap && hand_off)
