@@ -251,29 +251,30 @@ def main(argv=None):
     # the last one is completed inside the timed region.  (Single-process form: the gather is inside render_into.)
     film_gather = FilmGather(HEIGHT, WIDTH, band_rows, rank, world, comm_dev, always_collective=True) if dist_path else None
 
-    # One process per GPU over RCCL: the steps are enqueued back to back -- render, pack and gather are ordered by the stream,
-    # nothing in a step needs the host (a rank's share of the job is ~1 ms at 8 GPUs; a host round trip per step would be
-    # several percent of it).  The counters and launch times are then read once, after the last step, and stand for every
-    # step (each step renders the same samples).  Every other mode synchronises and reads them per step.
-    async_steps = dist_path and args.backend == "nccl"
+    # The steps are enqueued back to back: render, (pack, gather) are ordered by the stream and nothing in a step needs the
+    # host; the library adds up the counters and HIP-event launch times of the renders enqueued since the last
+    # synchronisation (pathtrace_amd.h: PtStats), so they are read ONCE, after the last step, and cover every timed launch.
+    # (One process per GPU: a rank's share of the job is ~1 ms at 8 GPUs, a host round trip per step several percent of it.)
+    # The single-process multi-device form and the gloo rehearsal synchronise per step.
+    async_steps = mode == "single" or (dist_path and args.backend == "nccl")
 
-    def step(record, weight=1):
+    def step(last):
         ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
-        if not async_steps or record:
+        if not async_steps or last:
             ctx.sync()
         if dist_path:
             film_gather.start(lin.to(comm_dev), rgba.to(comm_dev))
-        if record:
+        if not async_steps or last:
             st = ctx.stats()
-            acc["vertices"] += st.vertices * weight
-            acc["shadow_rays"] += st.shadow_rays * weight
-            acc["samples"] += st.samples * weight
-            acc["bounce_ms"] += st.bounce_kernel_ms * weight
-            acc["launches"] += st.bounce_launches * weight
-            acc["total_ms"] += st.total_ms * weight
-            acc["p_vertices"] += st.primary_vertices * weight
-            acc["p_ms"] += st.primary_kernel_ms * weight
-            acc["p_launches"] += st.primary_launches * weight
+            acc["vertices"] += st.vertices
+            acc["shadow_rays"] += st.shadow_rays
+            acc["samples"] += st.samples
+            acc["bounce_ms"] += st.bounce_kernel_ms
+            acc["launches"] += st.bounce_launches
+            acc["total_ms"] += st.total_ms
+            acc["p_vertices"] += st.primary_vertices
+            acc["p_ms"] += st.primary_kernel_ms
+            acc["p_launches"] += st.primary_launches
 
     def barrier():
         if dist_path:
@@ -284,18 +285,17 @@ def main(argv=None):
             torch.cuda.synchronize(d)
 
     frame = frame8 = None
-    for _ in range(args.warmup):
-        step(False)
+    for k in range(args.warmup):
+        step(k + 1 == args.warmup)
+    for key in acc:                             # the warm-up steps are not part of the statistics
+        acc[key] = 0 if isinstance(acc[key], int) else 0.0
     if dist_path:
         film_gather.finish()
     barrier()
     device_sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if async_steps:
-            step(k + 1 == args.steps, weight=args.steps)
-        else:
-            step(True)
+        step(k + 1 == args.steps)
     if dist_path:
         frame, frame8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
     device_sync()

@@ -137,7 +137,10 @@ typedef struct {
     uint32_t regen_workgroups;/* workgroups of that regenerating launch (0: what the device holds at once)             */
 } PtTuning;
 
-/* Counters of the last render on a context. */
+/* Counters of the renders enqueued on a context since they were last collected (pt_sync / pt_get_stats; pt_scene_upload
+ * starts afresh): normally ONE render -- synchronise after each and these are its counters.  A caller that pipelines several
+ * pt_render_device calls behind one synchronisation gets their sums; total_ms then runs from the first one's start to the
+ * last one's end. */
 typedef struct {
     uint64_t samples;          /* camera samples traced = tile pixels * spp    */
     uint64_t vertices;         /* path vertices processed (iterations of the

@@ -165,8 +165,8 @@ struct PtContext {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     PtStats stats{};
     bool stats_pending = false;
-    uint32_t profiled_batches = 0;
-    std::vector<uint32_t> primary_events;      // launch indices of the level-0 launches
+    uint32_t profiled_batches = 0;             // event slots (launch begin / end pairs) in use since the statistics were last collected
+    std::vector<uint32_t> primary_events;      // slots of the level-0 launches
     PtTuning tuning{};                         // pt_context_set_tuning; 0 = library default
     bool bvh_failed = false;                   // the BVH builder refused this scene (depth): PT_ACCEL_AUTO stays with the scan
     // pixel-list entries (pt_render_pixels, pt_ray_color)
@@ -463,6 +463,7 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     if ((rc = c->runs.ensure(runs.size() + 1))) return rc;
     if ((rc = c->lights.ensure(lights.size() + 1))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));   // the previous scene may still be in use
+    c->stats_pending = false;                    // statistics of renders of the previous scene do not carry over
     if (!scan.empty()) HIP_TRY(hipMemcpy(c->scan.p, scan.data(), scan.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->shape.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat.p, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -565,7 +566,15 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
 
     const uint64_t np64 = list ? list->n : (uint64_t)pt_tile_rows(cam->height, prm->band_rows, prm->band_index, band_count) * cam->width;
     const uint64_t tile_rows = list ? ((np64 + 65535u) >> 16) : np64 / cam->width;
-    std::memset(&c->stats, 0, sizeof c->stats);
+    // Statistics belong to the renders enqueued since they were last collected (pt_sync / pt_get_stats): a caller that
+    // pipelines several renders behind one synchronisation gets their sums (vertices, launches, kernel times), total_ms from
+    // the first one's start to the last one's end.  One render per synchronisation: the statistics of that render, as ever.
+    const bool accumulate = c->stats_pending;
+    if (!accumulate) {
+        std::memset(&c->stats, 0, sizeof c->stats);
+        c->profiled_batches = 0;
+        c->primary_events.clear();
+    }
     if (np64 == 0) return PT_OK;   // empty tile: nothing to render
     if (!d_linear) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer is null");
     if (!list && (cam->width > 65535u || tile_rows > 65535u))   // (tile row, x) share one word of the path state
@@ -698,10 +707,15 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const bool profile = prm->profile != 0;
     // statistics and the first batch's counters sit side by side: one fill for both
     const size_t first_counters = hand_off ? (regen ? kCountStride : 1u) : 0u;
-    HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, (kStatsWords + first_counters) * sizeof(uint32_t), st));
-    HIP_TRY(hipEventRecord(c->ev_begin, st));
+    if (!accumulate) {
+        HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, (kStatsWords + first_counters) * sizeof(uint32_t), st));
+        HIP_TRY(hipEventRecord(c->ev_begin, st));
+    } else if (first_counters) {      // the device-side counters keep adding up; only the launch counters start from zero
+        HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords, 0, first_counters * sizeof(uint32_t), st));
+    }
     uint32_t launches = 0;
-    c->primary_events.clear();
+    const uint32_t ev0 = c->profiled_batches;      // first free event slot
+    uint32_t primary_count = 0;
 
     hipStream_t side = overlap ? c->side_stream : st;
     if (overlap) {      // the side stream starts after whatever the caller's stream holds so far (previous renders, film state)
@@ -760,14 +774,14 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             }
             if (level == 0 && hand_off && batch > 0) HIP_TRY(hipMemsetAsync(d_count, 0, (regen ? kCountStride : 1u) * sizeof(uint32_t), ls));
             if (profile) {
-                if ((rc = ensure_events(c, 2 * (size_t)(launches + 1)))) return rc;
-                HIP_TRY(hipEventRecord(c->ev_pool[2 * launches], ls));
+                if ((rc = ensure_events(c, 2 * (size_t)(ev0 + launches + 1)))) return rc;
+                HIP_TRY(hipEventRecord(c->ev_pool[2 * (ev0 + launches)], ls));
             }
             if (prm->exact_math) ptk::launch_paths_exact(a, g, ls);
             else ptk::launch_paths_fast(a, g, ls);
-            if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * launches + 1], ls));
+            if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (ev0 + launches) + 1], ls));
             HIP_TRY(hipGetLastError());
-            if (level == 0) c->primary_events.push_back(launches);
+            if (level == 0) { ++primary_count; if (profile) c->primary_events.push_back(ev0 + launches); }
             ++launches;
             if (overlap && level == 0) {     // the tail of this batch (side stream) starts when its level-0 launch is through
                 HIP_TRY(hipEventRecord(c->ev_l0[par], st));
@@ -792,12 +806,12 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
     HIP_TRY(hipEventRecord(c->ev_end, st));
     HIP_TRY(hipMemcpyAsync(c->h_dstats, d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    c->stats.samples = (uint64_t)np * spp;
-    c->stats.bounce_launches = launches;
-    c->stats.batches = n_batches;
-    c->stats.primary_launches = (uint32_t)c->primary_events.size();
+    c->stats.samples += (uint64_t)np * spp;
+    c->stats.bounce_launches += launches;
+    c->stats.batches += n_batches;
+    c->stats.primary_launches += primary_count;
 
-    c->profiled_batches = profile ? launches : 0;
+    if (profile) c->profiled_batches = ev0 + launches;
     c->stats_pending = true;
     return PT_OK;
 }

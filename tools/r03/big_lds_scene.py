@@ -18,7 +18,7 @@ for form, wg in ((1, 0), (0, 0), (2, 1536), (2, 1280), (2, 1024), (2, 768)):
         e0.record(st)
         for _ in range(5): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         e1.record(st); st.synchronize()
-    ctx.sync(); s = ctx.stats()
+    ctx.sync(); ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr()); ctx.sync(); s = ctx.stats()      # the statistics of ONE render
     same = "" if ref is None else f", film == queue form: {bool(torch.equal(lin, ref))}"
     if ref is None: ref = lin.clone()
     print(f"{len(objs)} spheres, level0_form {form}, regen_workgroups {wg or 'default'}: {e0.elapsed_time(e1) / 5:.3f} ms per render, {s.bounce_launches} path launches{same}", flush=True)

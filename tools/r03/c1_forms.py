@@ -18,6 +18,6 @@ for spec in sys.argv[1:]:
         for _ in range(8): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         e1.record(st); st.synchronize()
     ms = e0.elapsed_time(e1) / 8
-    ctx.sync(); s = ctx.stats()
+    ctx.sync(); ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr()); ctx.sync(); s = ctx.stats()      # the statistics of ONE render
     print(f"{os.environ.get('PATHTRACE_AMD_LIB', 'default lib')}: scene {scene} level0_form {spec}: {ms:.3f} ms per render, {s.bounce_launches} path launches", flush=True)
     ctx.set_stream(None); ctx.close()

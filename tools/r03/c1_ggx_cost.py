@@ -26,7 +26,7 @@ for label, lambert in (("C1 (glass sphere)", False), ("C1 with a Lambertian sphe
             for _ in range(8): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
             e1.record(st); st.synchronize()
         ms = e0.elapsed_time(e1) / 8
-        ctx.sync(); s = ctx.stats()
+        ctx.sync(); ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr()); ctx.sync(); s = ctx.stats()      # the statistics of ONE render
         print(f"{label}, level0_form {form}: {ms:.3f} ms per render, {s.vertices / 1e6:.1f} M vertices, "
               f"{ms * 1e3 / (s.vertices / 1e6):.2f} us per M vertices, {s.bounce_launches} path launches", flush=True)
         ctx.set_stream(None); ctx.close()

@@ -27,7 +27,7 @@ for form in (1, 2, 3, 0):
         e0.record(st)
         for _ in range(6): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         e1.record(st); st.synchronize()
-    ctx.sync(); s = ctx.stats()
+    ctx.sync(); ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr()); ctx.sync(); s = ctx.stats()      # the statistics of ONE render
     same = "" if ref is None else f", film == queue form: {bool(torch.equal(lin, ref))}"
     if ref is None: ref = lin.clone()
     print(f"all-Mirror Cornell, level0_form {form}: {e0.elapsed_time(e1) / 6:.3f} ms per render, {s.vertices / 1e6:.0f} M vertices, {s.bounce_launches} path launches{same}", flush=True)

@@ -21,6 +21,6 @@ for form in (1, 2, 0):
         e0.record(st)
         for _ in range(8): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         e1.record(st); st.synchronize()
-    ctx.sync(); s = ctx.stats()
+    ctx.sync(); ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr()); ctx.sync(); s = ctx.stats()      # the statistics of ONE render
     print(f"OrenNayar Cornell, level0_form {form}: {e0.elapsed_time(e1) / 8:.3f} ms per render, {s.bounce_launches} path launches", flush=True)
     ctx.set_stream(None); ctx.close()

@@ -21,6 +21,6 @@ for k, (w, h, spp) in enumerate([(256, 256, 4), (512, 512, 2), (512, 512, 8), (1
         for _ in range(20): ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         e1.record(st); st.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    ctx.sync(); s = ctx.stats()
+    ctx.sync(); ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr()); ctx.sync(); s = ctx.stats()      # the statistics of ONE render
     print(f"form {form}: {w}x{h}x{spp} = {w*h*spp/1e6:.2f} M paths: {ms:.3f} ms  ({w*h*spp/ms/1e3:.0f} Msamples/s, {s.bounce_launches} path launches)", flush=True)
 ctx.set_stream(None); ctx.close()
