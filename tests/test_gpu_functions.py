@@ -385,6 +385,38 @@ def test_regenerating_form_with_ragged_batches_and_bands(pt, gpu_ctx, scene, for
         assert (st.vertices, st.shadow_rays, st.max_depth_reached, st.batches) == (base.vertices, base.shadow_rays, base.max_depth_reached, base.batches)
 
 
+def test_statistics_add_up_over_pipelined_renders(pt, gpu_ctx):
+    """PtStats cover the renders enqueued since they were last collected: one render per synchronisation gives that render's
+    counters; three renders enqueued behind ONE synchronisation give their sums (vertices, shadow rays, samples, launches,
+    batches; the launch times of all of them with profile = 1), and the film is the last render's.  A new scene starts afresh."""
+    import torch
+    gpu_ctx.upload(pt.builtin_scene(1))
+    cam = pt.camera_new(width=256, height=256)
+    prms = [pt.default_params(spp=6, profile=1), pt.default_params(spp=6, spp_offset=6, profile=1), pt.default_params(spp=9, spp_offset=50, profile=1)]
+    singles = []
+    for prm in prms:
+        lin, rgba = gpu_ctx.render(cam, prm)                 # render + pt_sync
+        singles.append((lin.clone(), gpu_ctx.stats()))
+    dev = lin.device
+    lin = torch.empty_like(lin); rgba = torch.empty((256, 256, 4), dtype=torch.uint8, device=dev)
+    for prm in prms:
+        gpu_ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())       # no synchronisation in between
+    gpu_ctx.sync()
+    st = gpu_ctx.stats()
+    assert torch.equal(lin, singles[-1][0])
+    for name in ("vertices", "shadow_rays", "samples", "bounce_launches", "batches", "primary_launches", "primary_vertices"):
+        assert getattr(st, name) == sum(getattr(s, name) for _, s in singles), name
+    assert st.max_depth_reached == max(s.max_depth_reached for _, s in singles)
+    assert st.primary_kernel_ms > 0 and abs(st.primary_kernel_ms - sum(s.primary_kernel_ms for _, s in singles)) < 0.5 * st.primary_kernel_ms
+    # collected: the next render starts from zero again; so does a new scene
+    lin2, _ = gpu_ctx.render(cam, prms[0])
+    assert gpu_ctx.stats().vertices == singles[0][1].vertices
+    gpu_ctx.render_into(cam, prms[0], lin.data_ptr(), rgba.data_ptr())
+    gpu_ctx.upload(pt.builtin_scene(1))
+    lin3, _ = gpu_ctx.render(cam, prms[0])
+    assert gpu_ctx.stats().vertices == singles[0][1].vertices and torch.equal(lin3, lin2)
+
+
 def torch_equal(a, b):
     import torch
     return torch.equal(a, b)
