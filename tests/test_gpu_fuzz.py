@@ -81,6 +81,39 @@ def test_random_scene_matches_f32_oracle(pt, orc, gpu_ctx, seed):
         assert ok[fin].mean() >= 0.97, (seed, ok[fin].mean())
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_DIRECT_SEEDS", "6"))))
+def test_random_scene_regenerating_default_matches_f32_oracle(pt, orc, gpu_ctx, seed):
+    """The regenerating kernels pinned DIRECTLY to the f32 oracle (the test below pins them to the queue form, which the test
+    above pins to the oracle): random scenes in LDS at 200 x 200 x 4..6 spp = 160 000 .. 240 000 paths, above the 2^17
+    threshold from which a batch takes a regenerating form by default -- k_paths_regen compiled for the scene's material set
+    (diffuse only / no Mirror / every material) or k_paths_regen_split where a minority of the objects is Mirror.  exact_math = 1:
+    film, RGBA8, vertex and shadow-ray counts equal the oracle's bit for bit, NaNs included."""
+    rng = np.random.default_rng(5000 + seed)
+    objs = random_scene(pt, rng, int(rng.integers(3, 40)))
+    kind = seed % 3
+    for o in objs:
+        if kind == 0 and o.mat_tag not in (0, 1):          # Lambertian / emissive only
+            o.mat_tag = 0
+            o.mat[0], o.mat[1], o.mat[2] = 0.6, 0.5, 0.4
+        if kind == 1 and o.mat_tag == 2:                    # no Mirror: the GGX objects become OrenNayar
+            o.mat_tag = 3
+            o.mat[0], o.mat[1], o.mat[2], o.mat[3] = 0.6, 0.5, 0.4, 0.5
+    cam = pt.camera_look_at(tuple(rng.uniform([-0.8, -0.8, 0.5], [0.8, 0.8, 2.5])), (0.0, 0.0, -2.0), (0.0, 1.0, 0.0),
+                            200, 200, float(rng.uniform(25, 60)))
+    prm = pt.default_params(spp=int(rng.integers(4, 7)), integrator=int(rng.integers(0, 2)),
+                            min_depth=int(rng.integers(0, 6)), max_depth=int(rng.integers(6, 30)), exact_math=1, accel=0)
+    gpu_ctx.upload(objs)
+    lin, rgba = gpu_ctx.render(cam, prm)
+    st = gpu_ctx.stats()
+    assert st.bounce_launches == 1 and st.batches == 1          # one regenerating launch, no continuation launch
+    ref, ref8, cnt = orc.render(cam, objs, prm, F32, ITER, 8)
+    got = lin.cpu().numpy()
+    assert np.array_equal(got, ref.astype(np.float32), equal_nan=True), \
+        f"seed {seed}: {(got != ref.astype(np.float32)).any(-1).sum()} pixels differ"
+    assert np.array_equal(rgba.cpu().numpy(), ref8)
+    assert st.vertices == cnt["vertices"] and st.shadow_rays == cnt["shadow_rays"] and st.max_depth_reached == cnt["max_depth"]
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_REGEN_SEEDS", "6"))))
 def test_random_scene_regenerating_form_equals_queue_form(pt, gpu_ctx, seed):
     """The regenerating level-0 kernel on random scenes (all four materials or diffuse only, several lights, random camera,
