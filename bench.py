@@ -196,6 +196,9 @@ def main(argv=None):
 
     mode, world, rank, local_rank = launch_mode(args.gpus, os.environ, args.force_dist, args.force_multi)
 
+    # the pool's host driver only supports dmabuf IPC: without this RCCL / cross-process device memory fails with
+    # "hipIpcGetMemHandle: invalid argument" (it is exported on the boxes already; kept for environments built by hand)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import pathtrace_amd as pt
