@@ -417,6 +417,29 @@ def test_statistics_add_up_over_pipelined_renders(pt, gpu_ctx):
     assert gpu_ctx.stats().vertices == singles[0][1].vertices and torch.equal(lin3, lin2)
 
 
+@pytest.mark.parametrize("scene", [1, 2])
+def test_tiny_images_with_many_samples_take_the_regenerating_forms(pt, gpu_ctx, scene):
+    """Batches above 2^17 paths take a regenerating form whatever the image size: images of a few pixels with tens of
+    thousands of samples (a 64-path chunk then spans many samples of the same pixels; s_local up to 65534; two batches
+    beyond that; a row band) equal the queue form -- films, counters, deepest vertex."""
+    gpu_ctx.upload(pt.builtin_scene(scene))
+    try:
+        for (w, h, spp, kw) in [(2, 2, 40000, {}), (3, 5, 20000, {}), (7, 3, 65535, {}), (2, 2, 70000, {}),
+                                (33, 17, 700, dict(band_rows=5, band_index=1, band_count=2))]:
+            cam = pt.camera_new(width=w, height=h)
+            prm = pt.default_params(spp=spp, **kw)
+            gpu_ctx.set_tuning(level0_form=1)
+            ref, ref8 = gpu_ctx.render(cam, prm)
+            base = gpu_ctx.stats()
+            gpu_ctx.set_tuning()
+            lin, rgba = gpu_ctx.render(cam, prm)
+            st = gpu_ctx.stats()
+            assert torch_equal(lin, ref) and torch_equal(rgba, ref8), (w, h, spp)
+            assert (st.vertices, st.shadow_rays, st.max_depth_reached, st.batches) == (base.vertices, base.shadow_rays, base.max_depth_reached, base.batches)
+    finally:
+        gpu_ctx.set_tuning()
+
+
 def torch_equal(a, b):
     import torch
     return torch.equal(a, b)
