@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 typedef enum {
     PT_OK = 0,
@@ -95,7 +95,7 @@ typedef struct {
     /* Wavefront sizing: upper bound on paths resident in HBM at once (0 = library default).  It sizes the
      * context's device buffers, which persist between renders: the default is 2^26 paths (76 B of queue + 12 B of
      * sample buffer each, only as many as the job has) and 2^28 where the level-0 launch keeps its paths in
-     * registers (diffuse scenes of <= 128 objects: 12 B of sample buffer per path, i.e. up to 3.2 GB per context
+     * registers (EVERY scene of <= 128 objects, whatever its materials: 12 B of sample buffer per path, i.e. up to 3.2 GB per context
      * for a render of >= 2^28 samples -- the 400 x 400 x 3000 default job included).  A host that shares the GPU
      * sets a smaller bound: the job is then cut into more sample batches, with the same film.                */
     uint64_t max_paths_in_flight;
@@ -209,7 +209,7 @@ int pt_scene_upload(PtContext* ctx, const PtObject* objs, uint32_t n_objs);
  *   d_linear_rgb: float[tile_rows*W*3], mean linear radiance  (= luminance_data,
  *                 src/world.rs:318-319)
  *   d_rgba8:      uint8[tile_rows*W*4], sqrt-gamma + truncation (= World.data /
- *                 draw(), src/world.rs:322-341); may be NULL.
+ *                 draw(), src/world.rs:322-341); may be NULL; 4-byte aligned (a pixel is one 32-bit store).
  * Work is enqueued on the context's stream and the call returns once the last launch is
  * enqueued; the continuation launch that finishes the sparse tails of a sample batch takes
  * its path count from device memory, so the host never waits inside.  Renders of several
@@ -219,6 +219,11 @@ int pt_scene_upload(PtContext* ctx, const PtObject* objs, uint32_t n_objs);
  * nothing and can be captured into a hipGraph.  pt_sync() waits.                          */
 int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params,
                      float* d_linear_rgb, uint8_t* d_rgba8);
+/* The same render, the film written as ONE 16-byte record per tile pixel -- float linear RGB (12 B) + RGBA8 (4 B), row-major
+ * like the planes -- into d_packed (tile_rows*W*16 bytes, 16-byte aligned): the send buffer of the multi-GPU film gather
+ * straight from the film resolve, without the two planes and the pt_film_pack launch in between.  pt_film_unpack (below)
+ * turns gathered records into the planes.  Asynchronous like pt_render_device.                                       */
+int pt_render_device_packed(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params, void* d_packed);
 int pt_sync(PtContext* ctx);
 int pt_get_stats(PtContext* ctx, PtStats* out);
 
@@ -248,23 +253,41 @@ void pt_shutdown(void);
 /* ---- multi-GPU ------------------------------------------------
  * ONE process drives n devices: one context per device, interleaved row bands (device g renders the bands b with
  * b % n == g; pixels are independent units keyed by (x, y), src/main.rs:51, so there is no collective on the data
- * path), and ONE RCCL gather (ncclGather, rccl.h:745, inside one ncclGroupStart/End) of the 16 B/pixel film tiles
- * to the first device over xGMI.  The frame is bitwise independent of n.  RCCL is loaded with dlopen by
- * pt_multi_create; hosts that render on one GPU never need it.  Not internally synchronised: one thread at a time. */
+ * path), and ONE RCCL gather (ncclGather, rccl.h:745) of the 16 B/pixel film tiles -- written by each device's film
+ * resolve straight into its send buffer -- to the first device over xGMI.  The frame is bitwise independent of n.
+ * RCCL is loaded with dlopen by pt_multi_create; hosts that render on one GPU never need it.
+ * Host threads: with more than one device every device is fed by its own host thread (its render launches, its
+ * ncclGather call on its own communicator), so the per-device enqueue costs overlap and pt_multi_render_device
+ * returns as soon as the frame is posted; frames posted back to back are kept apart by stream order on every device.
+ * An error of a posted frame is reported by the next pt_multi_sync / pt_multi_get_stats.  pt_multi_set_threads(m, 0)
+ * selects the one-thread form instead (the caller's thread enqueues every device, the gather calls inside one
+ * ncclGroupStart/End).  The object itself is not internally synchronised: call it from one thread at a time.        */
 typedef struct PtMulti PtMulti;
-int pt_multi_create(const int* devices, uint32_t n_devices, PtMulti** out);   /* contexts + ncclCommInitAll (rccl.h:236) */
+int pt_multi_create(const int* devices, uint32_t n_devices, PtMulti** out);   /* contexts + ncclCommInitAll (rccl.h:236) + one 16-byte gather that connects the ranks */
 int pt_multi_destroy(PtMulti* m);
 uint32_t pt_multi_device_count(const PtMulti* m);
+int pt_multi_set_threads(PtMulti* m, int enabled);
 int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs);  /* replicated on every device */
 int pt_multi_set_tuning(PtMulti* m, const PtTuning* tuning);                   /* pt_context_set_tuning on every device's context */
-/* Enqueue one frame: d_linear_rgb (H*W*3 floats) / d_rgba8 (H*W*4 bytes or NULL) are buffers on the FIRST device.
- * params->band_rows = 0 picks about eight bands per device; band_index / band_count are ignored.            */
+/* Post one frame: d_linear_rgb (H*W*3 floats) / d_rgba8 (H*W*4 bytes or NULL) are buffers on the FIRST device.
+ * params->band_rows = 0 picks about eight bands per device; band_index / band_count are ignored.  Asynchronous.   */
 int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams* params,
                            float* d_linear_rgb, uint8_t* d_rgba8);
-int pt_multi_sync(PtMulti* m);
-int pt_multi_get_stats(PtMulti* m, PtStats* out);    /* counters summed over the devices, times of the slowest */
+int pt_multi_sync(PtMulti* m);                       /* every posted frame is complete on every device */
+int pt_multi_get_stats(PtMulti* m, PtStats* out);    /* counters of the frames since the last collection summed over the devices, times of the slowest */
 int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* params,
                          float* out_linear_rgb, uint8_t* out_rgba8);
+/* What the object is made of -- a record of an N-device run carries these to show that N ranks took part.          */
+typedef struct {
+    uint32_t n_devices;
+    uint32_t comm_count;      /* ncclCommCount (rccl.h) of the first device's communicator; 0: a debug object without RCCL */
+    uint32_t rccl_version;    /* ncclGetVersion, e.g. 22203                                                         */
+    uint32_t threaded;        /* 1: one host thread per device                                                      */
+    uint64_t frames;          /* frames posted since creation                                                       */
+    double   enqueue_us_sum;  /* host time spent enqueueing one frame, summed over the devices (mean per frame) ...  */
+    double   enqueue_us_max;  /* ... and the slowest device's share of it: what a frame costs the host with threads  */
+} PtMultiInfo;
+int pt_multi_info(PtMulti* m, PtMultiInfo* out);
 /* One shot with host buffers (a cached PtMulti for the device list; pt_shutdown frees it). */
 int pt_render_multi(const int* devices, uint32_t n_devices, const PtCamera* cam, const PtObject* objs,
                     uint32_t n_objs, const PtRenderParams* params, float* out_linear_rgb, uint8_t* out_rgba8);
@@ -284,9 +307,20 @@ int pt_film_unpack(void* hip_stream, const void* d_gathered, uint32_t width, uin
                    uint32_t n_ranks, uint32_t max_rows, float* d_linear_rgb, uint8_t* d_rgba8);
 
 /* Debug / parity entry: the frame of an n_virtual-device render on ONE context (tiles rendered one after another,
- * device-to-device copies where pt_multi_* runs ncclGather): partition, pack and unpack for any n on a one-GPU box. */
+ * device-to-device copies where pt_multi_* runs ncclGather): partition, packed resolve and unpack for any n on a one-GPU box. */
 int pt_debug_multi_emulate(PtContext* ctx, uint32_t n_virtual, const PtCamera* cam, const PtRenderParams* params,
                            float* out_linear_rgb, uint8_t* out_rgba8);
+/* Debug object: a PtMulti of n contexts that all sit on ONE device, without RCCL -- each context copies its tile into the
+ * receive buffer on its own stream where the real object calls ncclGather.  Everything else is the real thing: the host
+ * threads, frames posted back to back, the packed resolve, the row permutation, the statistics.  Rehearses (and times:
+ * pt_multi_info) an n-device frame on a one-GPU box.                                                                */
+int pt_debug_multi_create_shared(int device, uint32_t n, PtMulti** out);
+/* Host-only self test of the per-device feeder threads (no GPU needed): posts n_frames jobs to each of n_workers threads
+ * the way pt_multi_render_device posts frames and returns the start / end log of the jobs in order_out (2 * n_workers *
+ * n_frames entries: worker << 32 | frame, bit 63 set on the end record); fail_at >= 0 makes job worker * n_frames + frame
+ * fail, and the call then returns the status the drain reported.                                                     */
+int pt_debug_feeder_selftest(uint32_t n_workers, uint32_t n_frames, uint32_t spin, int32_t fail_at,
+                             uint64_t* order_out, uint32_t* n_out);
 
 /* World::render_pixel (src/world.rs:293-333) -- the seam the reference's rayon loop calls at
  * src/main.rs:55 -- for an arbitrary list of n pixels: xy = n * (x, y), y = film row (top-down, the y

@@ -632,6 +632,9 @@ inline void sphere_sample(const Obj<R>& s, const Hit<R>& from, const Hit<R>* tar
             normal = (point - s.center).normalize();
             dir = direction;
             dist = t;
+            // observer inside the sphere: the near root is negative, the point is behind the cone direction; the reference
+            // returns (point - from).normalize() and its length (shape.rs:139-144) = -direction, |t|
+            if (dist < R(0)) { dir = -dir; dist = -dist; }
             return;
         } else {
             V3<R> up = std::fabs(w.y) > R(0.999) ? V3<R>(1, 0, 0) : V3<R>(0, 1, 0);

@@ -81,6 +81,18 @@ class PtStats(C.Structure):
     ]
 
 
+class PtMultiInfo(C.Structure):
+    _fields_ = [
+        ("n_devices", C.c_uint32),
+        ("comm_count", C.c_uint32),
+        ("rccl_version", C.c_uint32),
+        ("threaded", C.c_uint32),
+        ("frames", C.c_uint64),
+        ("enqueue_us_sum", C.c_double),
+        ("enqueue_us_max", C.c_double),
+    ]
+
+
 PT_SHAPE_SPHERE, PT_SHAPE_TRIANGLE = 0, 1
 PT_MAT_LAMBERT, PT_MAT_EMISSIVE, PT_MAT_MIRROR, PT_MAT_OREN_NAYAR = 0, 1, 2, 3
 PT_INTEGRATOR_MIS, PT_INTEGRATOR_BRDF_ONLY = 0, 1
@@ -101,6 +113,7 @@ SYMBOLS = {
     "pt_context_set_tuning": (C.c_int, [C.c_void_p, _P(PtTuning)]),
     "pt_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
     "pt_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_render_device_packed": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p]),
     "pt_sync": (C.c_int, [C.c_void_p]),
     "pt_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
     "pt_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
@@ -126,6 +139,10 @@ SYMBOLS = {
     "pt_multi_create": (C.c_int, [_P(C.c_int), C.c_uint32, _P(C.c_void_p)]),
     "pt_multi_destroy": (C.c_int, [C.c_void_p]),
     "pt_multi_device_count": (C.c_uint32, [C.c_void_p]),
+    "pt_multi_set_threads": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_multi_info": (C.c_int, [C.c_void_p, _P(PtMultiInfo)]),
+    "pt_debug_multi_create_shared": (C.c_int, [C.c_int, C.c_uint32, _P(C.c_void_p)]),
+    "pt_debug_feeder_selftest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _P(C.c_uint64), _P(C.c_uint32)]),
     "pt_multi_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
     "pt_multi_set_tuning": (C.c_int, [C.c_void_p, _P(PtTuning)]),
     "pt_multi_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),

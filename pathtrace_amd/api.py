@@ -118,6 +118,10 @@ class Context:
         check(lib().pt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(linear_ptr),
                                      C.c_void_p(rgba_ptr) if rgba_ptr else None))
 
+    def render_packed_into(self, cam, params, packed_ptr):
+        """pt_render_device_packed: the tile as 16 B per pixel (linear RGB + RGBA8), the send-buffer form of the film gather."""
+        check(lib().pt_render_device_packed(self._h, C.byref(cam), C.byref(params), C.c_void_p(packed_ptr)))
+
     def sync(self):
         check(lib().pt_sync(self._h))
 
@@ -271,12 +275,26 @@ for _n, _f in vars(_ContextFunctions).items():
 class Multi:
     """pt_multi_*: ONE process, several GPUs, one RCCL gather of the film to the first device."""
 
-    def __init__(self, devices):
-        arr = (C.c_int * len(devices))(*devices)
+    def __init__(self, devices, shared_device=None):
+        """devices: HIP ordinals (distinct).  shared_device = d: the DEBUG object of len(devices) contexts that all sit on
+        device d, the gather emulated by device-to-device copies (pt_debug_multi_create_shared; no RCCL)."""
         self._h = C.c_void_p()
-        check(lib().pt_multi_create(arr, len(devices), C.byref(self._h)))
+        if shared_device is not None:
+            check(lib().pt_debug_multi_create_shared(shared_device, len(devices), C.byref(self._h)))
+            devices = [shared_device] * len(devices)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            check(lib().pt_multi_create(arr, len(devices), C.byref(self._h)))
         self.devices = list(devices)
         self._objs = None
+
+    def set_threads(self, enabled):
+        check(lib().pt_multi_set_threads(self._h, 1 if enabled else 0))
+
+    def info(self):
+        i = _lib.PtMultiInfo()
+        check(lib().pt_multi_info(self._h, C.byref(i)))
+        return i
 
     def close(self):
         if self._h:

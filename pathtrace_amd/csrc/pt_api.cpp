@@ -165,6 +165,12 @@ struct PtContext {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     PtStats stats{};
     bool stats_pending = false;
+    // the device-side counters: the render statistics are zero (cleared when they were last collected) / the launch
+    // counters of batch parity 0, 1 are zero (the resolve of the batch that used them last cleared them) -- a render
+    // then needs no memset in the stream
+    bool stats_clean = false;
+    bool counters_clean[2] = {false, false};
+    uint32_t regen_occ[2][2][2] = {};          // cached occupancy query [exact_math][integrator][split] of this scene (0: not asked yet)
     uint32_t profiled_batches = 0;             // event slots (launch begin / end pairs) in use since the statistics were last collected
     std::vector<uint32_t> primary_events;      // slots of the level-0 launches
     PtTuning tuning{};                         // pt_context_set_tuning; 0 = library default
@@ -464,6 +470,8 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     if ((rc = c->lights.ensure(lights.size() + 1))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));   // the previous scene may still be in use
     c->stats_pending = false;                    // statistics of renders of the previous scene do not carry over
+    c->stats_clean = false;                      // (their device-side counters are cleared by the next render)
+    std::memset(c->regen_occ, 0, sizeof c->regen_occ);
     if (!scan.empty()) HIP_TRY(hipMemcpy(c->scan.p, scan.data(), scan.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->shape.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->mat.p, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -539,7 +547,7 @@ namespace {
 // The render driver behind every rendering entry: everything src/main.rs:43-60 does for the tile (or, with `list`,
 // for a pixel list / a set of given rays).  Enqueues on the context's streams and returns; no host synchronisation.
 int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, const FilmState& fs, const ListRender* list,
-                float* d_linear, uint8_t* d_rgba) {
+                float* d_linear, uint8_t* d_rgba, void* d_packed = nullptr) {
     if (!c || !cam || !prm) return fail(PT_ERR_INVALID_ARG, "render: null argument");
     if (!c->has_scene) return fail(PT_ERR_INVALID_ARG, "render: no scene uploaded");
     const bool inject = list && list->inject[0];
@@ -576,7 +584,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         c->primary_events.clear();
     }
     if (np64 == 0) return PT_OK;   // empty tile: nothing to render
-    if (!d_linear) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer is null");
+    if (!d_linear && !d_packed) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer is null");
     if (!list && (cam->width > 65535u || tile_rows > 65535u))   // (tile row, x) share one word of the path state
         return fail(PT_ERR_UNSUPPORTED, "tile %ux%llu: width and tile rows must be < 65536", cam->width, (unsigned long long)tile_rows);
     // scene / job that can take the regenerating level-0 kernel (decided below, once the batch size is known)
@@ -631,7 +639,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         q.sc = view_for(c, prm->exact_math);
         q.integrator = prm->integrator;
         q.xchg = split ? reinterpret_cast<float4*>(1) : nullptr;       // selects the kernel only
-        const uint32_t occ = prm->exact_math ? ptk::regen_blocks_per_cu_exact(q) : ptk::regen_blocks_per_cu_fast(q);
+        uint32_t& occ = c->regen_occ[prm->exact_math ? 1 : 0][prm->integrator ? 1 : 0][split ? 1 : 0];   // per scene (pt_scene_upload clears it)
+        if (occ == 0u) occ = prm->exact_math ? ptk::regen_blocks_per_cu_exact(q) : ptk::regen_blocks_per_cu_fast(q);
         if (occ != 0u) regen_per_cu = std::min(regen_per_cu, occ);
     }
     const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups :
@@ -658,7 +667,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (prm->accel && ((rc = c->bvh_aux.ensure(q_slots)) || (rc = c->bvh_sray[0].ensure(q_slots)) ||
                        (rc = c->bvh_sray[1].ensure(q_slots))))
         return rc;
-    if (regen && split && (rc = c->xchg.ensure((size_t)regen_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024)))   // + slack: a violated stack
+    // (sized by the grid the launch really takes: never more workgroups than the largest batch has chunks for)
+    const uint32_t regen_launch_grid = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (regen && split && (rc = c->xchg.ensure((size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024)))   // + slack: a violated stack
         return rc;                                                                                                         // invariant (reported) stays inside the buffer
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
@@ -705,14 +716,20 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     a.bvh_leaf = c->tuning.bvh_leaf ? c->tuning.bvh_leaf : ptk::kLeafBatch;
 
     const bool profile = prm->profile != 0;
-    // statistics and the first batch's counters sit side by side: one fill for both
-    const size_t first_counters = hand_off ? (regen ? kCountStride : 1u) : 0u;
+    // The device-side words are normally zero already: the statistics were cleared when they were last collected
+    // (pt_sync), the launch counters by the resolve of the batch that used them last (ResolveArgs.zero_words).  Only a
+    // fresh or re-allocated buffer, a new scene or a render that failed half-way leaves something to clear here.
+    const uint32_t launch_words = hand_off ? (regen ? kCountStride : 1u) : 0u;
     if (!accumulate) {
-        HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, (kStatsWords + first_counters) * sizeof(uint32_t), st));
+        if (!c->stats_clean) HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), st));
+        c->stats_clean = false;
         HIP_TRY(hipEventRecord(c->ev_begin, st));
-    } else if (first_counters) {      // the device-side counters keep adding up; only the launch counters start from zero
-        HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords, 0, first_counters * sizeof(uint32_t), st));
     }
+    for (int par = 0; par < (overlap ? 2 : 1); ++par)
+        if (launch_words && !c->counters_clean[par]) {
+            HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords + kCountStride * par, 0, kCountStride * sizeof(uint32_t), st));
+            c->counters_clean[par] = true;
+        }
     uint32_t launches = 0;
     const uint32_t ev0 = c->profiled_batches;      // first free event slot
     uint32_t primary_count = 0;
@@ -772,7 +789,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 const uint32_t nwr = g * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;
                 a.regen_static = (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
             }
-            if (level == 0 && hand_off && batch > 0) HIP_TRY(hipMemsetAsync(d_count, 0, (regen ? kCountStride : 1u) * sizeof(uint32_t), ls));
+            if (hand_off) c->counters_clean[par] = false;       // until this batch's resolve has cleared them again
             if (profile) {
                 if ((rc = ensure_events(c, 2 * (size_t)(ev0 + launches + 1)))) return rc;
                 HIP_TRY(hipEventRecord(c->ev_pool[2 * (ev0 + launches)], ls));
@@ -798,14 +815,17 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         r.store_film = batch + 1 < n_batches || fs.store;
         r.finalize = batch + 1 == n_batches;
         r.spp_div = fs.div ? fs.div : spp;
+        r.out_packed = d_packed;
+        if (launch_words) { r.zero_words = d_count; r.n_zero = launch_words; }
         ptk::launch_resolve(r, side);
         HIP_TRY(hipGetLastError());
+        if (launch_words) c->counters_clean[par] = true;
         if (overlap) HIP_TRY(hipEventRecord(c->ev_resolved[par], side));
     }
     if (overlap)        // the caller's stream is complete when the last resolve is (the side stream is in order)
         HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
     HIP_TRY(hipEventRecord(c->ev_end, st));
-    HIP_TRY(hipMemcpyAsync(c->h_dstats, d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    // (the device-side statistics are read when they are collected -- pt_sync --, not copied back per render)
     c->stats.samples += (uint64_t)np * spp;
     c->stats.bounce_launches += launches;
     c->stats.batches += n_batches;
@@ -823,6 +843,13 @@ extern "C" {
 int pt_render_device(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, float* d_linear, uint8_t* d_rgba) {
     return render_impl(c, cam, prm, FilmState{}, nullptr, d_linear, d_rgba);
 }
+// The same render with the film written as ONE 16-byte record per tile pixel (12 B linear RGB + 4 B RGBA8): the send buffer of
+// the multi-GPU gather, straight from the resolve (what pt_film_pack makes of the two planes in a launch of its own).
+int pt_render_device_packed(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, void* d_packed) {
+    if (!d_packed) return fail(PT_ERR_INVALID_ARG, "pt_render_device_packed: the output buffer is null");
+    if ((uintptr_t)d_packed % 16u) return fail(PT_ERR_INVALID_ARG, "pt_render_device_packed: the output buffer must be 16-byte aligned");
+    return render_impl(c, cam, prm, FilmState{}, nullptr, nullptr, nullptr, d_packed);
+}
 
 }  // extern "C"
 hipStream_t pt_internal_stream(PtContext* c) { return c->stream; }
@@ -833,6 +860,10 @@ int pt_sync(PtContext* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->stats_pending) {
+        // the device-side statistics of the renders since the last collection: read now (the stream is idle) and cleared
+        // for the next ones, so that no render carries a copy or a fill of them in its stream
+        HIP_TRY(hipMemcpy(c->h_dstats, c->ovf_count.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        c->stats_clean = hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), c->stream) == hipSuccess;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.total_ms = ms;
         double kms = 0.0;

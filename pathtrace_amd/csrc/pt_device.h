@@ -243,6 +243,8 @@ PT_DEV void frame_of(f3 n, f3& tangent, f3& bitangent) {
 // light_dir = direction and distance = t, and t is the near root of the cone ray in the cone's own coordinates,
 // t = dc cos(theta) - sqrt(r^2 - dc^2 sin^2(theta)) with dc = |center - from| (same real numbers as the reference's
 // quadratic, shape.rs:130-137; no second normalisation, no quadratic on world coordinates: -2 sqrt/rcp, -25 VALU).
+// For an observer INSIDE the sphere that root is negative: direction and sign are then flipped at the end, which is
+// what the reference's point - from gives there.
 PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float r1, float r2, f3& point,
                           float& pdf_omega, f3& dir, float& dist) {
     f3 center = mk(r0.x, r0.y, r0.z);
@@ -274,6 +276,9 @@ PT_DEV void sphere_sample(float4 r0, f3 from, bool with_target, f3 target, float
     float disc = __builtin_fmaf(-distance_sq, sin2_theta, radius * radius);
     dist = __builtin_fmaf(dc, cos_theta, -pt_sqrt(__builtin_fmaxf(disc, 0.0f)));
     point = madd(dir, dist, from);
+    // `from` inside the sphere (an enclosing light: dc < r): the near root is negative, the point lies BEHIND the cone
+    // direction, and what rendering.rs:58-60 derives from it is distance = |t|, light_dir = -direction (shape.rs:139-144)
+    if (dist < 0.0f) { dir = -dir; dist = -dist; }
 }
 // TriangleShape::sample_surface_from_point, shape.rs:200-242; dir / dist as above (here the reference itself forms
 // them, :218-221, and rendering.rs:58-60 forms the same values again)

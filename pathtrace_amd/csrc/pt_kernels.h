@@ -176,6 +176,13 @@ struct ResolveArgs {
     uint32_t store_film;      // keep the sums in `film` (more samples follow)
     uint32_t finalize;        // write the outputs: mean over spp_div samples, gamma, quantisation
     uint32_t spp_div;
+    // non-null: the finalising pass writes ONE 16-byte record per pixel here (12 B linear RGB + 4 B RGBA8: the send
+    // buffer of the multi-GPU film gather) INSTEAD of the two planes -- what k_film_pack made of them in a second launch
+    void* out_packed;
+    // non-null: workgroup 0 clears these words (the chunk / hand-over counters of the batch just resolved, so that the
+    // next launch that uses them finds them zero without a memset of its own in the stream)
+    uint32_t* zero_words;
+    uint32_t n_zero;
 };
 void launch_resolve(const ResolveArgs& a, hipStream_t st);
 

@@ -1640,6 +1640,8 @@ namespace PTK_IMPL {
 // nb samples of the batch are added in sample order into an f64 sum, so the film
 // does not depend on how paths were scheduled.
 __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
+    if (blockIdx.x == 0u && a.zero_words)
+        for (uint32_t k = threadIdx.x; k < a.n_zero; k += kBlock) a.zero_words[k] = 0u;
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= a.np) return;
     double r = 0.0, g = 0.0, b = 0.0;
@@ -1651,17 +1653,25 @@ __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
     if (a.store_film) { a.film[3 * (size_t)p] = r; a.film[3 * (size_t)p + 1] = g; a.film[3 * (size_t)p + 2] = b; }
     if (!a.finalize) return;
     double c[3] = {r / (double)a.spp_div, g / (double)a.spp_div, b / (double)a.spp_div};   // world.rs:315
+    const bool want8 = a.out_rgba != nullptr || a.out_packed != nullptr;
+    uint32_t q8 = 0xFF000000u;                                                    // alpha 255, world.rs:331
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        a.out_linear[3 * (size_t)p + k] = (float)c[k];                            // luminance_data, world.rs:318-319
-        if (a.out_rgba) {
+        if (want8) {
             double gm = __builtin_sqrt(c[k]);                                     // gamma 2.0, world.rs:322-324
             double cl = gm < 0.0 ? 0.0 : (gm > 1.0 ? 1.0 : gm);                   // clamp keeps NaN
             double q = cl * 255.0;
-            a.out_rgba[4 * (size_t)p + k] = (q != q) ? (uint8_t)0 : (uint8_t)q;   // `as u8`: truncation, NaN -> 0
+            q8 |= (uint32_t)((q != q) ? (uint8_t)0 : (uint8_t)q) << (8 * k);      // `as u8`: truncation, NaN -> 0
         }
     }
-    if (a.out_rgba) a.out_rgba[4 * (size_t)p + 3] = 255;                          // world.rs:331
+    if (a.out_packed) {       // the multi-GPU send record: both film planes of the pixel in one 16-byte store
+        reinterpret_cast<uint4*>(a.out_packed)[p] = make_uint4(__float_as_uint((float)c[0]), __float_as_uint((float)c[1]),
+                                                               __float_as_uint((float)c[2]), q8);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.out_linear[3 * (size_t)p + k] = (float)c[k];   // luminance_data, world.rs:318-319
+    if (a.out_rgba) *reinterpret_cast<uint32_t*>(a.out_rgba + 4 * (size_t)p) = q8;
 }
 }  // namespace PTK_IMPL
 #if !PT_MATH_EXACT

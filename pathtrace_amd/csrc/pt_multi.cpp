@@ -3,10 +3,20 @@
 //
 // Every pixel is an independent unit whose RNG key is a pure function of (x, y) (src/main.rs:51) and whose result
 // lands in its own film slot (src/main.rs:58, world.rs:318); the scene is tiny and replicated.  So device g renders
-// the bands b with b % n == g (pt_render_device, band_* of PtRenderParams) with no data-path collective, packs its
-// tile to 16 B per pixel (linear RGB + RGBA8) and all devices meet in one ncclGather (rccl.h:745) inside an
-// ncclGroupStart/End of the one host thread; the root then puts the gathered rows in image order.  The frame is
-// bitwise independent of the number of devices.
+// the bands b with b % n == g (band_* of PtRenderParams) with no data-path collective, its film resolve writes the tile
+// as 16 B per pixel (linear RGB + RGBA8: pt_render_device_packed) straight into the send buffer, and all devices meet in
+// one ncclGather (rccl.h:745); the root then puts the gathered rows in image order.  The frame is bitwise independent
+// of the number of devices.
+//
+// Host side (round 4): every device has its own host thread (pt_feeder.h) that enqueues its share of a frame -- the
+// render, its ncclGather call (one communicator per thread, the standard one-thread-per-device use of RCCL), on the
+// root also the row permutation -- so the per-device enqueue times overlap instead of adding up, and
+// pt_multi_render_device returns as soon as the frame is posted: a caller may post frame k + 1 while the devices still
+// run frame k.  What keeps frames apart is stream order alone: on device g the send buffer of frame k + 1 is written by a
+// resolve that follows frame k's gather in g's stream, and on the root the receive buffer is written by a gather that
+// follows frame k's row permutation in the root's stream.  pt_multi_sync() waits for the threads, then for the streams.
+// pt_multi_set_threads(m, 0) restores the one-thread form (every device enqueued by the caller, the n ncclGather calls
+// inside one ncclGroupStart/End).
 //
 // RCCL is opened with dlopen the first time a multi-device object is created: a host that renders on one GPU never
 // needs the library, and a process that already holds an RCCL (torch) keeps using that one.
@@ -14,13 +24,17 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/pathtrace_amd.h"
+#include "pt_feeder.h"
 #include "pt_kernels.h"
 
 // defined in pt_api.cpp
@@ -34,6 +48,8 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -54,13 +70,15 @@ int load_rccl() {
     r.handle = h;
     r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(h, "ncclGetVersion");
     r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
     r.Gather = (decltype(r.Gather))dlsym(h, "ncclGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Gather || !r.GetErrorString)
         return pt_internal_fail(PT_ERR_UNSUPPORTED, "multi-GPU: the RCCL library lacks ncclCommInitAll / ncclGather");
-    g_rccl = r;
+    g_rccl = r;       // ncclCommCount / ncclGetVersion are optional (pt_multi_info reports 0 without them)
     return PT_OK;
 }
 
@@ -96,28 +114,140 @@ struct DevMem {
 // Band height giving every device about eight interleaved bands (the cost of a pixel depends on what it sees)
 uint32_t default_band_rows(uint32_t height, uint32_t n) { return std::max(1u, height / std::max(1u, n * 8u)); }
 
+// Geometry of one frame over n devices
+struct FrameShape {
+    uint32_t W, H, n, band_rows, max_rows;
+    size_t tile_px;              // pixels of the padded tile every device sends
+};
+FrameShape frame_shape(const PtCamera* cam, const PtRenderParams* prm, uint32_t n) {
+    FrameShape f;
+    f.W = cam->width; f.H = cam->height; f.n = n;
+    f.band_rows = prm->band_rows ? prm->band_rows : default_band_rows(f.H, n);
+    f.max_rows = 0;
+    for (uint32_t g = 0; g < n; ++g) f.max_rows = std::max(f.max_rows, pt_tile_rows(f.H, f.band_rows, g, n));
+    f.tile_px = std::max<size_t>((size_t)f.max_rows * f.W, 1);
+    return f;
+}
+
 }  // namespace
 
 struct PtMulti {
     std::vector<int> devices;
     std::vector<PtContext*> ctx;
-    std::vector<ncclComm_t> comm;
-    std::vector<DevMem> lin, rgba, packed;     // per device: its tile (f32 RGB, RGBA8) and the 16 B/pixel send buffer
+    std::vector<ncclComm_t> comm;              // shared-device debug objects: none
+    std::vector<DevMem> packed;                // per device: the 16 B/pixel send buffer its film resolve writes
     DevMem recv, out_lin, out_rgba;            // root: gathered tiles; frame staging of the host entry
+    std::unique_ptr<ptfeed::Feeder> feeder;    // one host thread per device; null: the caller's thread enqueues every device
+    uint64_t frames = 0;                       // frames posted since creation
+    std::mutex info_mu;
+    std::vector<double> enqueue_us;            // per device: host time spent enqueueing its share, summed over the frames
+    // Debug object (pt_debug_multi_create_shared): every context on ONE device, no RCCL -- each context copies its tile
+    // into the receive buffer on its own stream where the real object runs ncclGather.  Host latches keep the emulation's
+    // events in frame order (the collective does that by itself).
+    bool shared = false;
+    std::vector<hipEvent_t> ev_copied;
+    hipEvent_t ev_unpacked = nullptr;
+    std::mutex lat_mu;
+    std::condition_variable lat_cv;
+    std::vector<uint64_t> copied_frame;
+    uint64_t unpacked_frame = 0;
 };
+
+namespace {
+
+int multi_drain(PtMulti* m) {
+    if (!m->feeder) return PT_OK;
+    std::string err;
+    const int rc = m->feeder->drain(&err);
+    if (rc) return pt_internal_fail(rc, "%s", err.c_str());
+    return PT_OK;
+}
+
+// Device g's share of frame `frame`: the render into its send buffer and its part of the gather.  Runs on g's feeder thread
+// (or on the caller's).  defer_gather: the caller issues the n ncclGather calls itself, inside one group.
+int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderParams& prm, const FrameShape& fs, uint64_t frame,
+                   bool defer_gather) {
+    HIP_TRY(hipSetDevice(m->devices[g]));
+    PtRenderParams p = prm;
+    p.band_rows = fs.band_rows; p.band_index = g; p.band_count = fs.n;
+    const int rc = pt_render_device_packed(m->ctx[g], &cam, &p, m->packed[g].p);      // an empty tile renders nothing
+    if (rc) return rc;
+    hipStream_t st = pt_internal_stream(m->ctx[g]);
+    if (m->shared) {
+        // emulated gather: the tile goes to its place in the receive buffer once the row permutation of the previous
+        // frame has read it
+        if (frame > 1) {
+            std::unique_lock<std::mutex> lk(m->lat_mu);
+            m->lat_cv.wait(lk, [&] { return m->unpacked_frame + 1 >= frame; });
+            lk.unlock();
+            HIP_TRY(hipStreamWaitEvent(st, m->ev_unpacked, 0));
+        }
+        HIP_TRY(hipMemcpyAsync((char*)m->recv.p + (size_t)g * fs.tile_px * 16, m->packed[g].p, fs.tile_px * 16, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipEventRecord(m->ev_copied[g], st));
+        { std::lock_guard<std::mutex> lk(m->lat_mu); m->copied_frame[g] = frame; }
+        m->lat_cv.notify_all();
+    } else if (!defer_gather) {
+        // this device's call of THE gather (ncclGather, rccl.h:745): its communicator, its stream, its thread
+        NCCL_TRY(g_rccl.Gather(m->packed[g].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], st));
+    }
+    return PT_OK;
+}
+
+// The root's tail of a frame: rows into image order, behind the gather in the root's stream
+int enqueue_root_tail(PtMulti* m, const FrameShape& fs, uint64_t frame, float* d_linear, uint8_t* d_rgba) {
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    hipStream_t st = pt_internal_stream(m->ctx[0]);
+    if (m->shared) {
+        {
+            std::unique_lock<std::mutex> lk(m->lat_mu);
+            m->lat_cv.wait(lk, [&] { for (uint64_t f : m->copied_frame) if (f < frame) return false; return true; });
+        }
+        for (uint32_t g = 1; g < fs.n; ++g) HIP_TRY(hipStreamWaitEvent(st, m->ev_copied[g], 0));
+    }
+    ptk::launch_film_unpack(m->recv.p, fs.W, fs.H, fs.band_rows, fs.n, fs.max_rows, d_linear, d_rgba, st);
+    HIP_TRY(hipGetLastError());
+    if (m->shared) {
+        HIP_TRY(hipEventRecord(m->ev_unpacked, st));
+        { std::lock_guard<std::mutex> lk(m->lat_mu); m->unpacked_frame = frame; }
+        m->lat_cv.notify_all();
+    }
+    return PT_OK;
+}
+
+int multi_alloc(uint32_t n, const int* devices, bool shared, PtMulti** out) {
+    PtMulti* m = new PtMulti();
+    m->devices.assign(devices, devices + n);
+    m->ctx.assign(n, nullptr);
+    m->packed.resize(n);
+    m->enqueue_us.assign(n, 0.0);
+    m->shared = shared;
+    int rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((rc = pt_context_create(devices[i], &m->ctx[i]))) { pt_multi_destroy(m); return rc; }
+        m->packed[i].device = devices[i];
+    }
+    m->recv.device = m->out_lin.device = m->out_rgba.device = devices[0];
+    *out = m;
+    return PT_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
 int pt_multi_destroy(PtMulti* m) {
     if (!m) return PT_OK;
+    (void)multi_drain(m);
+    m->feeder.reset();                          // joins the threads: nothing touches the contexts from here on
     for (size_t i = 0; i < m->ctx.size(); ++i) {
         if (m->ctx[i]) (void)pt_sync(m->ctx[i]);
     }
     for (ncclComm_t c : m->comm) if (c) (void)g_rccl.CommDestroy(c);
-    for (auto& b : m->lin) b.release();
-    for (auto& b : m->rgba) b.release();
     for (auto& b : m->packed) b.release();
     m->recv.release(); m->out_lin.release(); m->out_rgba.release();
+    if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
+    for (hipEvent_t e : m->ev_copied) if (e) (void)hipEventDestroy(e);
+    if (m->ev_unpacked) (void)hipEventDestroy(m->ev_unpacked);
     for (PtContext* c : m->ctx) if (c) (void)pt_context_destroy(c);
     delete m;
     return PT_OK;
@@ -131,31 +261,110 @@ int pt_multi_create(const int* devices, uint32_t n, PtMulti** out) {
             if (devices[i] == devices[j]) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_multi_create: device %d listed twice", devices[i]);
     int rc = load_rccl();
     if (rc) return rc;
-    PtMulti* m = new PtMulti();
-    m->devices.assign(devices, devices + n);
-    m->ctx.assign(n, nullptr); m->comm.assign(n, nullptr);
-    m->lin.resize(n); m->rgba.resize(n); m->packed.resize(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        if ((rc = pt_context_create(devices[i], &m->ctx[i]))) { pt_multi_destroy(m); return rc; }
-        m->lin[i].device = m->rgba[i].device = m->packed[i].device = devices[i];
-    }
-    m->recv.device = m->out_lin.device = m->out_rgba.device = devices[0];
+    PtMulti* m = nullptr;
+    if ((rc = multi_alloc(n, devices, false, &m))) return rc;
+    m->comm.assign(n, nullptr);
     const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), (int)n, devices);     // rccl.h:236
     if (r != ncclSuccess) {
         for (auto& c : m->comm) c = nullptr;
         pt_multi_destroy(m);
         return pt_internal_fail(PT_ERR_HIP, "ncclCommInitAll over %u device(s) failed: %s", n, g_rccl.GetErrorString(r));
     }
+    // One 16-byte gather now, from this thread, inside a group: RCCL connects a pair of ranks at their first exchange,
+    // and doing that here keeps the (blocking) connection set-up out of the per-device threads and out of the first frame.
+    {
+        auto warm = [&]() -> int {
+            int rc2;
+            for (uint32_t g = 0; g < n; ++g) {
+                if ((rc2 = m->packed[g].ensure(16))) return rc2;
+                HIP_TRY(hipSetDevice(devices[g]));
+                HIP_TRY(hipMemsetAsync(m->packed[g].p, 0, 16, pt_internal_stream(m->ctx[g])));
+            }
+            if ((rc2 = m->recv.ensure(16 * (size_t)n))) return rc2;
+            NCCL_TRY(g_rccl.GroupStart());
+            for (uint32_t g = 0; g < n; ++g) {
+                const ncclResult_t rg = g_rccl.Gather(m->packed[g].p, m->recv.p, 16, ncclUint8, 0, m->comm[g], pt_internal_stream(m->ctx[g]));
+                if (rg != ncclSuccess) { (void)g_rccl.GroupEnd(); return pt_internal_fail(PT_ERR_HIP, "ncclGather (connection warm-up) failed on device %d: %s", devices[g], g_rccl.GetErrorString(rg)); }
+            }
+            NCCL_TRY(g_rccl.GroupEnd());
+            for (uint32_t g = 0; g < n; ++g) {
+                HIP_TRY(hipSetDevice(devices[g]));
+                HIP_TRY(hipStreamSynchronize(pt_internal_stream(m->ctx[g])));
+            }
+            return PT_OK;
+        };
+        if ((rc = warm())) { pt_multi_destroy(m); return rc; }
+    }
+    if (n > 1) m->feeder.reset(new ptfeed::Feeder(n));      // one device: nothing to overlap (pt_multi_set_threads(m, 1) for the rehearsal)
     *out = m;
+    return PT_OK;
+}
+
+// Debug object: n contexts on ONE device, the gather emulated by device-to-device copies -- host threads, frame
+// pipelining, the packed resolve, the row permutation and the per-device enqueue cost of an n-device frame on a one-GPU box.
+int pt_debug_multi_create_shared(int device, uint32_t n, PtMulti** out) {
+    if (!out || n == 0 || n > 64) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_debug_multi_create_shared: bad argument");
+    *out = nullptr;
+    std::vector<int> devs(n, device);
+    PtMulti* m = nullptr;
+    int rc;
+    if ((rc = multi_alloc(n, devs.data(), true, &m))) return rc;
+    m->copied_frame.assign(n, 0);
+    m->ev_copied.assign(n, nullptr);
+    auto events = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        for (uint32_t g = 0; g < n; ++g) HIP_TRY(hipEventCreateWithFlags(&m->ev_copied[g], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_unpacked, hipEventDisableTiming));
+        return PT_OK;
+    };
+    if ((rc = events())) { pt_multi_destroy(m); return rc; }
+    if (n > 1) m->feeder.reset(new ptfeed::Feeder(n));
+    *out = m;
+    return PT_OK;
+}
+
+// 1: one host thread per device feeds its stream (default for more than one device); 0: the calling thread enqueues every
+// device in turn and the gather calls form one ncclGroup.  Same frame either way.
+int pt_multi_set_threads(PtMulti* m, int enabled) {
+    if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
+    int rc = multi_drain(m);
+    if (rc) return rc;
+    if (enabled && !m->feeder) m->feeder.reset(new ptfeed::Feeder((unsigned)m->devices.size()));
+    if (!enabled) m->feeder.reset();
     return PT_OK;
 }
 
 uint32_t pt_multi_device_count(const PtMulti* m) { return m ? (uint32_t)m->devices.size() : 0u; }
 
+int pt_multi_info(PtMulti* m, PtMultiInfo* out) {
+    if (!m || !out) return pt_internal_fail(PT_ERR_INVALID_ARG, "null argument");
+    int rc = multi_drain(m);
+    if (rc) return rc;
+    PtMultiInfo info{};
+    info.n_devices = (uint32_t)m->devices.size();
+    info.threaded = m->feeder ? 1u : 0u;
+    info.frames = m->frames;
+    if (!m->comm.empty() && m->comm[0]) {
+        int cnt = 0, ver = 0;
+        if (g_rccl.CommCount && g_rccl.CommCount(m->comm[0], &cnt) == ncclSuccess) info.comm_count = (uint32_t)cnt;
+        if (g_rccl.GetVersion && g_rccl.GetVersion(&ver) == ncclSuccess) info.rccl_version = (uint32_t)ver;
+    }
+    std::lock_guard<std::mutex> lk(m->info_mu);
+    for (double us : m->enqueue_us) {
+        info.enqueue_us_sum += us;
+        info.enqueue_us_max = std::max(info.enqueue_us_max, us);
+    }
+    if (m->frames) { info.enqueue_us_sum /= (double)m->frames; info.enqueue_us_max /= (double)m->frames; }
+    *out = info;
+    return PT_OK;
+}
+
 int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs) {
     if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
+    int rc = multi_drain(m);
+    if (rc) return rc;
     for (PtContext* c : m->ctx) {
-        const int rc = pt_scene_upload(c, objs, n_objs);     // the scene is replicated (<= 160 KB for the reference's scenes)
+        rc = pt_scene_upload(c, objs, n_objs);     // the scene is replicated (<= 160 KB for the reference's scenes)
         if (rc) return rc;
     }
     return PT_OK;
@@ -163,65 +372,91 @@ int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs) {
 
 int pt_multi_set_tuning(PtMulti* m, const PtTuning* t) {
     if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
-    for (PtContext* c : m->ctx) { const int rc = pt_context_set_tuning(c, t); if (rc) return rc; }
+    int rc = multi_drain(m);
+    if (rc) return rc;
+    for (PtContext* c : m->ctx) { rc = pt_context_set_tuning(c, t); if (rc) return rc; }
     return PT_OK;
 }
 
-// Enqueue the whole frame: every device renders its bands, then the one gather, then the row permutation on the
-// first device, whose stream is complete when the frame is.  d_linear_rgb / d_rgba8: buffers on the FIRST device,
+// Post the whole frame: every device renders its bands, then the one gather, then the row permutation on the first
+// device, whose stream is complete when the frame is.  d_linear_rgb / d_rgba8: buffers on the FIRST device,
 // H*W*3 floats / H*W*4 bytes (d_rgba8 may be NULL).  params->band_rows = 0 picks about eight bands per device;
-// band_index / band_count of params are ignored (the object owns the partition).
+// band_index / band_count of params are ignored (the object owns the partition).  With host threads the call returns
+// once the frame is posted to them; an error of a device's enqueue is reported by the next pt_multi_sync / _get_stats.
 int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams* prm, float* d_linear, uint8_t* d_rgba) {
     if (!m || !cam || !prm || !d_linear) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_multi_render_device: null argument");
     const uint32_t n = (uint32_t)m->devices.size();
-    const uint32_t W = cam->width, H = cam->height;
-    const uint32_t band_rows = prm->band_rows ? prm->band_rows : default_band_rows(H, n);
-    uint32_t max_rows = 0;
-    for (uint32_t g = 0; g < n; ++g) max_rows = std::max(max_rows, pt_tile_rows(H, band_rows, g, n));
-    const size_t tile_px = (size_t)max_rows * W;
+    const FrameShape fs = frame_shape(cam, prm, n);
     int rc;
-    // 1. every device renders its interleaved bands into its own tile (no collective on the data path)
-    for (uint32_t g = 0; g < n; ++g) {
-        PtRenderParams p = *prm;
-        p.band_rows = band_rows; p.band_index = g; p.band_count = n;
-        const size_t px = (size_t)pt_tile_rows(H, band_rows, g, n) * W;
-        if ((rc = m->lin[g].ensure(std::max<size_t>(px, 1) * 3 * sizeof(float))) || (rc = m->rgba[g].ensure(std::max<size_t>(px, 1) * 4)) ||
-            (rc = m->packed[g].ensure(std::max<size_t>(tile_px, 1) * 16)))
-            return rc;
-        if ((rc = pt_render_device(m->ctx[g], cam, &p, (float*)m->lin[g].p, d_rgba ? (uint8_t*)m->rgba[g].p : nullptr))) return rc;
-        HIP_TRY(hipSetDevice(m->devices[g]));
-        ptk::launch_film_pack((const float*)m->lin[g].p, d_rgba ? (const uint8_t*)m->rgba[g].p : nullptr, (uint32_t)px, m->packed[g].p,
-                              pt_internal_stream(m->ctx[g]));
-        HIP_TRY(hipGetLastError());
+    // buffers: a larger frame than any before re-allocates -- not under the feet of frames still in flight
+    bool grow = m->recv.cap < fs.tile_px * 16 * n;
+    for (uint32_t g = 0; g < n; ++g) grow = grow || m->packed[g].cap < fs.tile_px * 16;
+    if (grow) {
+        if ((rc = pt_multi_sync(m))) return rc;
+        for (uint32_t g = 0; g < n; ++g)
+            if ((rc = m->packed[g].ensure(fs.tile_px * 16))) return rc;
+        if ((rc = m->recv.ensure(fs.tile_px * 16 * n))) return rc;
     }
-    if ((rc = m->recv.ensure(std::max<size_t>(tile_px, 1) * 16 * n))) return rc;
+    const uint64_t frame = ++m->frames;
+    const PtCamera cam_v = *cam;
+    const PtRenderParams prm_v = *prm;
+    auto timed = [m](uint32_t g, std::chrono::steady_clock::time_point t0) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(m->info_mu);
+        m->enqueue_us[g] += us;
+    };
+    if (m->feeder) {
+        // one job per device, on that device's thread; the root's job ends with the row permutation
+        for (uint32_t g = 0; g < n; ++g) {
+            m->feeder->post(g, [=](std::string& err) -> int {
+                const auto t0 = std::chrono::steady_clock::now();
+                int r = enqueue_device(m, g, cam_v, prm_v, fs, frame, false);
+                if (!r && g == 0) r = enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
+                if (r) err = pt_last_error();
+                timed(g, t0);
+                return r;
+            });
+        }
+        return PT_OK;
+    }
+    // one thread: 1. every device renders its interleaved bands into its send buffer (no collective on the data path)
+    for (uint32_t g = 0; g < n; ++g) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = enqueue_device(m, g, cam_v, prm_v, fs, frame, true))) return rc;
+        timed(g, t0);
+    }
     // 2. ONE gather of the padded tiles to the first device (ncclGather, rccl.h:745), every device on its own stream
-    NCCL_TRY(g_rccl.GroupStart());
-    for (uint32_t g = 0; g < n; ++g) {
-        const ncclResult_t r = g_rccl.Gather(m->packed[g].p, m->recv.p, tile_px * 16, ncclUint8, 0, m->comm[g], pt_internal_stream(m->ctx[g]));
-        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return pt_internal_fail(PT_ERR_HIP, "ncclGather failed on device %d: %s", m->devices[g], g_rccl.GetErrorString(r)); }
+    if (!m->shared) {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (uint32_t g = 0; g < n; ++g) {
+            const ncclResult_t r = g_rccl.Gather(m->packed[g].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], pt_internal_stream(m->ctx[g]));
+            if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return pt_internal_fail(PT_ERR_HIP, "ncclGather failed on device %d: %s", m->devices[g], g_rccl.GetErrorString(r)); }
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
     }
-    NCCL_TRY(g_rccl.GroupEnd());
     // 3. rows into image order on the first device
-    HIP_TRY(hipSetDevice(m->devices[0]));
-    ptk::launch_film_unpack(m->recv.p, W, H, band_rows, n, max_rows, d_linear, d_rgba, pt_internal_stream(m->ctx[0]));
-    HIP_TRY(hipGetLastError());
-    return PT_OK;
+    return enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
 }
 
 int pt_multi_sync(PtMulti* m) {
     if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
-    for (PtContext* c : m->ctx) { const int rc = pt_sync(c); if (rc) return rc; }
-    return PT_OK;
+    int rc = multi_drain(m);            // every posted frame is enqueued on the streams ...
+    for (PtContext* c : m->ctx) {       // ... and now complete on them
+        const int r2 = pt_sync(c);
+        if (!rc) rc = r2;
+    }
+    return rc;
 }
 
-// Counters of the last frame summed over the devices (times: the slowest device).
+// Counters of the frames since the last collection summed over the devices (times: the slowest device).
 int pt_multi_get_stats(PtMulti* m, PtStats* out) {
     if (!m || !out) return pt_internal_fail(PT_ERR_INVALID_ARG, "null argument");
+    int rc = multi_drain(m);
+    if (rc) return rc;
     PtStats t{};
     for (PtContext* c : m->ctx) {
         PtStats s{};
-        const int rc = pt_get_stats(c, &s);
+        rc = pt_get_stats(c, &s);
         if (rc) return rc;
         t.samples += s.samples; t.vertices += s.vertices; t.shadow_rays += s.shadow_rays;
         t.bounce_launches += s.bounce_launches; t.batches = std::max(t.batches, s.batches);
@@ -238,6 +473,8 @@ int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* 
     if (!m || !cam || !prm || !out_linear) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_multi_render_host: null argument");
     const size_t px = (size_t)cam->width * cam->height;
     int rc;
+    if (m->out_lin.cap < std::max<size_t>(px, 1) * 12 || (out_rgba && m->out_rgba.cap < std::max<size_t>(px, 1) * 4))
+        if ((rc = pt_multi_sync(m))) return rc;          // the staging buffers grow: not while a frame may still write them
     if ((rc = m->out_lin.ensure(std::max<size_t>(px, 1) * 3 * sizeof(float))) || (out_rgba && (rc = m->out_rgba.ensure(std::max<size_t>(px, 1) * 4)))) return rc;
     if ((rc = pt_multi_render_device(m, cam, prm, (float*)m->out_lin.p, out_rgba ? (uint8_t*)m->out_rgba.p : nullptr))) return rc;
     if ((rc = pt_multi_sync(m))) return rc;
@@ -248,40 +485,68 @@ int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* 
 }
 
 // Debug / parity entry: the frame of an n_virtual-device render produced on ONE context -- the n tiles are rendered one
-// after another on ctx's device, packed, placed in the gather buffer by device-to-device copies (where pt_multi_*
-// runs ncclGather) and put in image order by the same kernel.  Exercises partition, pack and unpack for any n on a
-// one-GPU box; host output buffers, blocking.
+// after another on ctx's device into the send-buffer form, placed in the gather buffer by device-to-device copies (where
+// pt_multi_* runs ncclGather) and put in image order by the same kernel.  Exercises partition, packed resolve and unpack
+// for any n on a one-GPU box; host output buffers, blocking.
 int pt_debug_multi_emulate(PtContext* ctx, uint32_t n_virtual, const PtCamera* cam, const PtRenderParams* prm, float* out_linear,
                            uint8_t* out_rgba) {
     if (!ctx || !cam || !prm || !out_linear || n_virtual == 0) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_debug_multi_emulate: bad argument");
-    const uint32_t n = n_virtual, W = cam->width, H = cam->height;
-    const uint32_t band_rows = prm->band_rows ? prm->band_rows : default_band_rows(H, n);
-    uint32_t max_rows = 0;
-    for (uint32_t g = 0; g < n; ++g) max_rows = std::max(max_rows, pt_tile_rows(H, band_rows, g, n));
-    const size_t tile_px = std::max<size_t>((size_t)max_rows * W, 1), px = std::max<size_t>((size_t)W * H, 1);
-    DevMem lin, rgba, packed, recv, olin, orgba;
-    struct Free { DevMem* m[6]; ~Free() { for (DevMem* x : m) x->release(); } } guard{{&lin, &rgba, &packed, &recv, &olin, &orgba}};
+    const FrameShape fs = frame_shape(cam, prm, n_virtual);
+    const uint32_t n = n_virtual;
+    const size_t px = std::max<size_t>((size_t)fs.W * fs.H, 1);
+    DevMem packed, recv, olin, orgba;
+    struct Free { DevMem* m[4]; ~Free() { for (DevMem* x : m) x->release(); } } guard{{&packed, &recv, &olin, &orgba}};
     int rc;
-    if ((rc = lin.ensure(tile_px * 12)) || (rc = rgba.ensure(tile_px * 4)) || (rc = packed.ensure(tile_px * 16)) ||
-        (rc = recv.ensure(tile_px * 16 * n)) || (rc = olin.ensure(px * 12)) || (rc = orgba.ensure(px * 4)))
+    if ((rc = packed.ensure(fs.tile_px * 16)) || (rc = recv.ensure(fs.tile_px * 16 * n)) || (rc = olin.ensure(px * 12)) || (rc = orgba.ensure(px * 4)))
         return rc;
     hipStream_t st = pt_internal_stream(ctx);
     for (uint32_t g = 0; g < n; ++g) {
         PtRenderParams p = *prm;
-        p.band_rows = band_rows; p.band_index = g; p.band_count = n;
-        const size_t tp = (size_t)pt_tile_rows(H, band_rows, g, n) * W;
-        if ((rc = pt_render_device(ctx, cam, &p, (float*)lin.p, out_rgba ? (uint8_t*)rgba.p : nullptr))) return rc;
-        ptk::launch_film_pack((const float*)lin.p, out_rgba ? (const uint8_t*)rgba.p : nullptr, (uint32_t)tp, packed.p, st);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync((char*)recv.p + (size_t)g * tile_px * 16, packed.p, tile_px * 16, hipMemcpyDeviceToDevice, st));
-        if ((rc = pt_sync(ctx))) return rc;          // the tile buffers are reused by the next virtual device
+        p.band_rows = fs.band_rows; p.band_index = g; p.band_count = n;
+        if ((rc = pt_render_device_packed(ctx, cam, &p, packed.p))) return rc;
+        HIP_TRY(hipMemcpyAsync((char*)recv.p + (size_t)g * fs.tile_px * 16, packed.p, fs.tile_px * 16, hipMemcpyDeviceToDevice, st));
+        if ((rc = pt_sync(ctx))) return rc;          // the send buffer is reused by the next virtual device
     }
-    ptk::launch_film_unpack(recv.p, W, H, band_rows, n, max_rows, (float*)olin.p, out_rgba ? (uint8_t*)orgba.p : nullptr, st);
+    ptk::launch_film_unpack(recv.p, fs.W, fs.H, fs.band_rows, n, fs.max_rows, (float*)olin.p, out_rgba ? (uint8_t*)orgba.p : nullptr, st);
     HIP_TRY(hipGetLastError());
     if ((rc = pt_sync(ctx))) return rc;
-    HIP_TRY(hipMemcpy(out_linear, olin.p, (size_t)W * H * 12, hipMemcpyDeviceToHost));
-    if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, orgba.p, (size_t)W * H * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_linear, olin.p, (size_t)fs.W * fs.H * 12, hipMemcpyDeviceToHost));
+    if (out_rgba) HIP_TRY(hipMemcpy(out_rgba, orgba.p, (size_t)fs.W * fs.H * 4, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+// Host-only self test of the per-device feeder threads (pt_feeder.h), no GPU needed: n_workers threads, n_frames jobs
+// posted to each in frame order the way pt_multi_render_device posts a frame; job (w, f) appends its tag w << 32 | f to a
+// shared log when it STARTS and again (bit 63 set) when it ENDS, after `spin` iterations of busy work.  order_out (2 *
+// n_workers * n_frames entries) receives the log; fail_at >= 0: the job with that linear index w * n_frames + f fails, and
+// the function returns what drain() reported.  The caller checks per-worker FIFO order and cross-worker overlap.
+int pt_debug_feeder_selftest(uint32_t n_workers, uint32_t n_frames, uint32_t spin, int32_t fail_at, uint64_t* order_out, uint32_t* n_out) {
+    if (!order_out || !n_out || n_workers == 0 || n_workers > 64) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_debug_feeder_selftest: bad argument");
+    std::mutex mu;
+    std::vector<uint64_t> log;
+    log.reserve(2 * (size_t)n_workers * n_frames);
+    int rc;
+    {
+        ptfeed::Feeder feeder(n_workers);
+        for (uint32_t f = 0; f < n_frames; ++f)
+            for (uint32_t w = 0; w < n_workers; ++w)
+                feeder.post(w, [&, w, f](std::string& err) -> int {
+                    { std::lock_guard<std::mutex> lk(mu); log.push_back(((uint64_t)w << 32) | f); }
+                    volatile uint64_t x = 0;
+                    for (uint32_t k = 0; k < spin * (1u + (w + f) % 3u); ++k) x = x + k;
+                    { std::lock_guard<std::mutex> lk(mu); log.push_back((1ull << 63) | ((uint64_t)w << 32) | f); }
+                    if (fail_at >= 0 && (uint32_t)fail_at == w * n_frames + f) { err = "job " + std::to_string(fail_at) + " failed as asked"; return PT_ERR_HIP; }
+                    return PT_OK;
+                });
+        std::string err;
+        rc = feeder.drain(&err);
+        if (rc) (void)pt_internal_fail(rc, "%s", err.c_str());
+        std::string again;
+        if (feeder.drain(&again) != 0) return pt_internal_fail(PT_ERR_UNSUPPORTED, "feeder: a failure was reported twice");
+    }
+    *n_out = (uint32_t)log.size();
+    std::copy(log.begin(), log.end(), order_out);
+    return rc;
 }
 
 }  // extern "C"

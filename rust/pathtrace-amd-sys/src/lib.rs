@@ -1,9 +1,9 @@
-//! Raw declarations of `include/pathtrace_amd.h` (ABI version 2).  Field order, types and names follow the
+//! Raw declarations of `include/pathtrace_amd.h` (ABI version 3).  Field order, types and names follow the
 //! header exactly; `tests/test_rust_binding.py` checks that.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const PT_ABI_VERSION: u32 = 2;
+pub const PT_ABI_VERSION: u32 = 3;
 
 pub const PT_OK: c_int = 0;
 pub const PT_ERR_INVALID_ARG: c_int = 1;
@@ -93,6 +93,19 @@ pub struct PtStats {
     pub reserved2: u32,
 }
 
+/// `pt_multi_info`: what a multi-device object is made of.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtMultiInfo {
+    pub n_devices: u32,
+    pub comm_count: u32,
+    pub rccl_version: u32,
+    pub threaded: u32,
+    pub frames: u64,
+    pub enqueue_us_sum: f64,
+    pub enqueue_us_max: f64,
+}
+
 #[repr(C)]
 pub struct PtContext {
     _private: [u8; 0],
@@ -121,6 +134,7 @@ extern "C" {
     pub fn pt_context_set_tuning(ctx: *mut PtContext, tuning: *const PtTuning) -> c_int;
     pub fn pt_scene_upload(ctx: *mut PtContext, objs: *const PtObject, n_objs: u32) -> c_int;
     pub fn pt_render_device(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
+    pub fn pt_render_device_packed(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, d_packed: *mut c_void) -> c_int;
     pub fn pt_sync(ctx: *mut PtContext) -> c_int;
     pub fn pt_get_stats(ctx: *mut PtContext, out: *mut PtStats) -> c_int;
     pub fn pt_render_host(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
@@ -130,6 +144,10 @@ extern "C" {
     pub fn pt_multi_create(devices: *const c_int, n_devices: u32, out: *mut *mut PtMulti) -> c_int;
     pub fn pt_multi_destroy(m: *mut PtMulti) -> c_int;
     pub fn pt_multi_device_count(m: *const PtMulti) -> u32;
+    pub fn pt_multi_set_threads(m: *mut PtMulti, enabled: c_int) -> c_int;
+    pub fn pt_multi_info(m: *mut PtMulti, out: *mut PtMultiInfo) -> c_int;
+    pub fn pt_debug_multi_create_shared(device: c_int, n: u32, out: *mut *mut PtMulti) -> c_int;
+    pub fn pt_debug_feeder_selftest(n_workers: u32, n_frames: u32, spin: u32, fail_at: i32, order_out: *mut u64, n_out: *mut u32) -> c_int;
     pub fn pt_multi_scene_upload(m: *mut PtMulti, objs: *const PtObject, n_objs: u32) -> c_int;
     pub fn pt_multi_set_tuning(m: *mut PtMulti, tuning: *const PtTuning) -> c_int;
     pub fn pt_multi_render_device(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;

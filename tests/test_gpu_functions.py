@@ -270,7 +270,7 @@ def test_ray_color_on_arbitrary_rays(pt, orc, gpu_ctx, integrator):
 
 # ---------------------------------------------------------------- the entry is asynchronous / graph-capturable
 # (1, 1): queue-form level-0 launch + continuation launch; (1, 0): the reference scene's default, the regenerating form with
-# batched Mirror vertices; (2, 0): regenerating form (chunk counters reset by a memset node)
+# batched Mirror vertices; (2, 0): regenerating form (its chunk counters are cleared by the resolve of the same graph)
 @pytest.mark.parametrize("scene,form", [(1, 1), (1, 0), (2, 0)])
 def test_render_entry_is_capturable_into_a_graph(pt, gpu_ctx, scene, form):
     """pt_render_device enqueues and returns: no host synchronisation, no allocation once its buffers exist.  So it can
@@ -464,6 +464,24 @@ def test_multi_gpu_entry_with_one_device_over_rccl(pt, gpu_ctx):
             assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8), band_rows
         st = m.stats()
         assert st.samples == 200 * 117 * 6
+        info = m.info()
+        assert (info.n_devices, info.comm_count, info.threaded) == (1, 1, 0) and info.rccl_version >= 20000 and info.frames == 5
+        # the host-thread form (default for more than one device) over the real communicator: the device's own thread makes
+        # the render launches and the ncclGather call; three frames posted back to back, then ONE synchronisation
+        import torch
+        m.set_threads(True)
+        assert m.info().threaded == 1
+        dev = torch.device("cuda", 0)
+        outs = [(torch.zeros((117, 200, 3), dtype=torch.float32, device=dev), torch.zeros((117, 200, 4), dtype=torch.uint8, device=dev)) for _ in range(3)]
+        for k, (lin_d, rgba_d) in enumerate(outs):
+            m.render_into(cam, pt.default_params(spp=6, band_rows=[7, 0, 64][k]), lin_d.data_ptr(), rgba_d.data_ptr())
+        m.sync()
+        for lin_d, rgba_d in outs:
+            assert np.array_equal(lin_d.cpu().numpy(), ref) and np.array_equal(rgba_d.cpu().numpy(), ref8)
+        assert m.stats().samples == 3 * 200 * 117 * 6 and m.info().frames == 8
+        m.set_threads(False)
+        lin, rgba = m.render_host(cam, pt.default_params(spp=6, band_rows=3))
+        assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8)
     finally:
         m.close()
     lin, rgba = pt.render_multi([0], cam, objs, prm)
@@ -488,6 +506,77 @@ def test_multi_gpu_partition_pack_unpack_for_n_devices(pt, gpu_ctx, n):
     for band_rows in (0, 1, 10, 117):
         lin, rgba = gpu_ctx.multi_emulate(n, cam, pt.default_params(spp=5, band_rows=band_rows))
         assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8), (n, band_rows)
+
+
+@pytest.mark.parametrize("scene,kw", [(2, {}), (1, dict(band_rows=5, band_index=1, band_count=3)), (2, dict(max_paths_in_flight=300000)),
+                                      (1, dict(exact_math=1)), (4, dict(accel=1))])
+def test_packed_render_is_the_two_planes_packed(pt, gpu_ctx, scene, kw):
+    """pt_render_device_packed: the film resolve writes the 16 B/pixel send record of the multi-GPU gather itself.  Bit for bit
+    what pt_film_pack makes of the two planes of pt_render_device -- whole image, a row-band tile, several sample batches
+    (the f64 film sums in between), exact arithmetic, the BVH kernels."""
+    import torch
+    gpu_ctx.upload(pt.builtin_scene(scene, 300 if scene == 4 else 0))
+    cam = pt.camera_new(width=257, height=131)
+    prm = pt.default_params(spp=7, **kw)
+    lin, rgba = gpu_ctx.render(cam, prm)
+    rows = lin.shape[0]
+    packed = torch.zeros((rows, 257, 16), dtype=torch.uint8, device=lin.device)
+    gpu_ctx.render_packed_into(cam, prm, packed.data_ptr())
+    gpu_ctx.sync()
+    want = torch.empty_like(packed)
+    pt._lib.check(pt._lib.lib().pt_film_pack(None, lin.data_ptr(), rgba.data_ptr(), rows * 257, want.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(packed, want)
+    assert torch.equal(packed[..., :12].contiguous().view(torch.float32).reshape(rows, 257, 3), lin) and torch.equal(packed[..., 12:], rgba)
+    with pytest.raises(pt._lib.PtError, match="null"):
+        gpu_ctx.render_packed_into(cam, prm, 0)
+    with pytest.raises(pt._lib.PtError, match="aligned"):
+        gpu_ctx.render_packed_into(cam, prm, packed.data_ptr() + 4)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_n_device_frames_from_host_threads_posted_back_to_back(pt, gpu_ctx, n):
+    """The single-process multi-device object with n > 1 "devices" on this one-GPU box: n contexts on device 0
+    (pt_debug_multi_create_shared; device-to-device copies stand in for ncclGather, everything else is the real object).
+    One host thread per device feeds its stream; SIX frames (different sample offsets, band heights, with and without the
+    RGBA8 plane) are posted back to back and synchronised ONCE: every frame equals the one-context render of the same
+    parameters bit for bit, the statistics are the sums, and the one-thread form gives the same frames."""
+    import torch
+    objs = pt.builtin_scene(1)
+    gpu_ctx.upload(objs)
+    cam = pt.camera_new(width=192, height=117)
+    dev = torch.device("cuda", 0)
+    jobs = [dict(spp=5, spp_offset=3 * k, band_rows=[0, 1, 10, 117, 4, 33][k]) for k in range(6)]
+    refs, verts = [], 0
+    for j in jobs:
+        lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=j["spp"], spp_offset=j["spp_offset"]))
+        verts += gpu_ctx.stats().vertices
+        refs.append((lin.clone(), rgba.clone()))
+    m = pt.Multi([0] * n, shared_device=0)
+    try:
+        m.upload(objs)
+        for threaded in (True, False):
+            m.set_threads(threaded)
+            outs = [(torch.zeros((117, 192, 3), dtype=torch.float32, device=dev), torch.zeros((117, 192, 4), dtype=torch.uint8, device=dev)) for _ in jobs]
+            for k, (j, (lin_d, rgba_d)) in enumerate(zip(jobs, outs)):
+                m.render_into(cam, pt.default_params(**j), lin_d.data_ptr(), rgba_d.data_ptr() if k != 2 else 0)
+            m.sync()
+            for k, ((lin_d, rgba_d), (lin, rgba)) in enumerate(zip(outs, refs)):
+                assert torch.equal(lin_d, lin), (n, threaded, k)
+                assert k == 2 or torch.equal(rgba_d, rgba), (n, threaded, k)
+            st = m.stats()
+            assert st.samples == 6 * 192 * 117 * 5 and st.vertices == verts
+            info = m.info()
+            assert (info.n_devices, info.comm_count, info.threaded) == (n, 0, 1 if threaded else 0)
+            assert info.enqueue_us_max > 0 and info.enqueue_us_sum >= info.enqueue_us_max
+        # a larger frame re-allocates the exchange buffers between frames: still right
+        big = pt.camera_new(width=320, height=200)
+        m.set_threads(True)
+        lin_h, rgba_h = m.render_host(big, pt.default_params(spp=3))
+        ref, ref8 = gpu_ctx.render(big, pt.default_params(spp=3))
+        assert np.array_equal(lin_h, ref.cpu().numpy()) and np.array_equal(rgba_h, ref8.cpu().numpy())
+    finally:
+        m.close()
 
 
 def test_large_pixel_list_takes_the_tail_hand_off(pt, gpu_ctx):

@@ -120,6 +120,29 @@ def test_metal_and_oren_nayar_materials(pt, orc, gpu_ctx):
     _check(pt, orc, gpu_ctx, arr, pt.camera_new(width=64, height=64), pt.default_params(spp=8))
 
 
+def test_objects_inside_an_emissive_sphere(pt, orc, gpu_ctx):
+    """An enclosing light (sky dome): every NEE sample is taken from INSIDE the emissive sphere, where the cone
+    sampler's near root is negative (shape.rs:134-144).  Film bit-exact against the f32 oracle and within the FP32
+    tolerance of the f64 recursive oracle (whose light_dir / distance are the reference's own point - from); the
+    device function on its own as well.  (the f32 specification handed on a negative distance there.)"""
+    from test_oracle_integrator import enclosing_light_scene
+    objs = enclosing_light_scene(pt)
+    _, st = _check(pt, orc, gpu_ctx, objs, pt.camera_new(width=64, height=64), pt.default_params(spp=16))
+    assert st.shadow_rays > 0
+    rng = np.random.default_rng(6)
+    frm = rng.uniform([-1.5, -0.5, -4.0], [1.5, 2.0, 1.0], size=(4000, 3))
+    r12 = rng.uniform(0.0, 1.0, size=(4000, 2))
+    ref = orc.shape_sample(objs, frm, None, r12, F64)            # point3 normal3 pdf dir3 dist
+    s32 = orc.shape_sample(objs, frm, None, r12, F32)
+    for exact in (1, 0):
+        got = gpu_ctx.debug_shape_sample(0, frm, r12=r12, exact_math=exact).astype(np.float64)   # point3 pdf dir3 dist
+        assert (got[:, 7] > 0).all()
+        assert np.allclose(got[:, 0:3], ref[:, 0:3], atol=5e-5) and np.allclose(got[:, 4:7], ref[:, 7:10], atol=2e-5)
+        assert np.allclose(got[:, 7], ref[:, 10], rtol=2e-5, atol=1e-5)
+    got = gpu_ctx.debug_shape_sample(0, frm, r12=r12, exact_math=1)
+    assert np.array_equal(got[:, 4:8], s32[:, 7:11].astype(np.float32))
+
+
 def test_no_lights_and_empty_scene(pt, orc, gpu_ctx):
     objs = pt.make_objects([(0, [0, 0, -3, 1.0], 0, [0.5] * 3)])
     got, st = _check(pt, orc, gpu_ctx, objs, pt.camera_new(width=16, height=16), pt.default_params(spp=2))

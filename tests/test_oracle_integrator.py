@@ -165,3 +165,50 @@ def test_row_bands_partition_the_image(pt, orc):                  # pixels are i
         assert tile.shape[0] == len(rows)
         rebuilt[rows] = tile
     assert np.array_equal(rebuilt, full)
+
+
+def enclosing_light_scene(pt):
+    """Objects INSIDE an emissive sphere (a sky dome): every shading point has dc < r for the light, so the cone sampler's
+    near root is negative and the light point lies behind the cone direction (shape.rs:134-144)."""
+    return pt.make_objects([
+        (SPH, [0.0, 0.0, -2.0, 6.0], EMISSIVE, [0.8, 0.9, 1.0]),          # the dome; the camera (0, 0, 2) is inside too
+        (SPH, [0.0, -100.6, -2.0, 100.0], LAMBERT, [0.6, 0.6, 0.6]),      # floor: reaches outside the dome, visible part inside
+        (SPH, [-0.5, -0.2, -2.0, 0.4], LAMBERT, [0.8, 0.3, 0.3]),
+        (SPH, [0.5, -0.3, -1.6, 0.3], LAMBERT, [0.3, 0.8, 0.3]),
+        (SPH, [0.1, 0.5, -2.4, 0.35], MIRROR, [0.2, 0.9, 0.9, 0.9, 1.0, 1.5]),
+    ])
+
+
+def test_light_sample_from_inside_an_emissive_sphere(pt, orc):
+    """The f32 specification of SphereShape::sample_surface_from_point returns the cone direction and the near root as
+    (light_dir, distance); from inside the sphere that root is negative and the reference's own
+    (point - from).normalize() / .length() (shape.rs:139-144, rendering.rs:58-60) are -direction and |t|.  f32 and f64
+    oracle must agree on direction, distance and point there (round 3 handed on a negative distance: ADVICE r3)."""
+    objs = enclosing_light_scene(pt)
+    rng = np.random.default_rng(5)
+    n = 2000
+    frm = rng.uniform([-1.5, -0.5, -4.0], [1.5, 2.0, 1.0], size=(n, 3))     # all inside the dome
+    r12 = rng.uniform(0.0, 1.0, size=(n, 2))
+    a = orc.shape_sample(objs, frm, None, r12, F64)        # object 0 of the array = the dome
+    b = orc.shape_sample(objs, frm, None, r12, F32)
+    # out11 = point3, normal3, pdf_omega, light_dir3, distance
+    assert (a[:, 10] > 0).all() and (b[:, 10] > 0).all()
+    assert np.allclose(a[:, 10], b[:, 10], rtol=2e-5, atol=1e-5)
+    assert np.allclose(a[:, 7:10], b[:, 7:10], atol=2e-5)
+    assert np.allclose(a[:, 0:3], b[:, 0:3], atol=5e-5)
+    assert np.allclose(a[:, 6], 1.0 / (2.0 * np.pi)) and np.allclose(b[:, 6], 1.0 / (2.0 * np.pi), rtol=1e-6)
+    # the point is on the sphere and distance / direction are the point's
+    assert np.allclose(np.linalg.norm(a[:, 0:3] - np.array([0.0, 0.0, -2.0]), axis=1), 6.0, rtol=1e-9)
+    assert np.allclose(frm + a[:, 7:10] * a[:, 10:11], a[:, 0:3], atol=1e-9)
+
+
+def test_f32_film_inside_an_emissive_sphere_follows_f64(pt, orc):
+    objs = enclosing_light_scene(pt)
+    cam = pt.camera_new(width=48, height=48)
+    prm = pt.default_params(spp=16)
+    ref, ref8, _ = orc.render(cam, objs, prm, F64, REC, 8)
+    got, got8, c = orc.render(cam, objs, prm, F32, ITER, 8)
+    ok = (np.abs(got - ref) <= 1e-3 + 1e-2 * np.abs(ref)).all(-1)
+    assert ok.mean() >= 0.995, ok.mean()
+    assert abs(got.mean() - ref.mean()) <= 1e-3 * ref.mean()
+    assert c["shadow_rays"] > 0 and ref.mean() > 0.1
