@@ -52,13 +52,18 @@ WORKLOADS = {
     "c3": (2, 0, 1024, 1024, 4096, "C3: 10-sphere diffuse Cornell scene, steady state"),
     "c4": (4, 10000, 1024, 1024, 256, "C4: 10 000 random spheres (100 lights)"),
     "c5": (2, 0, 3840, 2160, 1024, "C5: 10-sphere diffuse Cornell scene, 4K"),
+    # the reference's literal job: World::new() at WIDTH = HEIGHT = 400, SAMPLE_NUM = 3000 (world.rs:16-18) -- the only
+    # configuration the reference itself ships; `host_buffers` in the JSON line is the same job through pt_render with HOST
+    # film buffers (main.rs:58-66 ends with the film on the host), PCIe included
+    "ref": (1, 0, 400, 400, 3000, "REF: World::new() as the reference ships it (world.rs:16-18)"),
 }
 BYTES_PER_VERTEX = 252      # extend 32 + shade 144 + shadow/accumulate 68 + compaction 8 (a five-kernel pipeline;
 BYTES_PER_SAMPLE = 64       # the fused kernel never makes those round trips: informational only)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
 VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector (= the f32 MFMA rate)
 F_SPHERE, F_TRIANGLE, F_SHADE = 23, 51, 200     # flops per primitive test / per shaded vertex (Lambert)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+REGEN_MIN_PATHS = 1 << 17     # pt_api.cpp kRegenMinPaths: batches above this over a scene in LDS take a regenerating form
 
 
 def launch_mode(gpus, env, force_dist=False, force_multi=False):
@@ -228,7 +233,11 @@ def main(argv=None):
     band_rows = default_band_rows(HEIGHT, world) if mode != "single" else 0
     tuning = dict(cont_workgroups=args.cont_workgroups, export_below=args.export_below, level0_form=args.level0_form,
                   regen_workgroups=args.regen_workgroups)
-    common = dict(spp=spp, profile=1, max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
+    # N = 1: every path-kernel launch of the timed steps is bracketed by HIP events (the roofline's launch time is measured
+    # live in the timed region).  N > 1: a rank's share of a step is ~1 ms, so the timed steps carry no per-launch events;
+    # the launch times for the roofline come from a few extra steps AFTER the timed region.
+    live_profile = 1 if world == 1 else 0
+    common = dict(spp=spp, profile=live_profile, max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
     if mode == "multi":
         # ONE process, `world` devices: every device renders its interleaved bands, ONE ncclGather to device 0 (pt_multi.cpp)
         prm = pt.default_params(band_rows=band_rows, **common)
@@ -258,14 +267,24 @@ def main(argv=None):
     # host; the library adds up the counters and HIP-event launch times of the renders enqueued since the last
     # synchronisation (pathtrace_amd.h: PtStats), so they are read ONCE, after the last step, and cover every timed launch.
     # (One process per GPU: a rank's share of the job is ~1 ms at 8 GPUs, a host round trip per step several percent of it.)
-    # The single-process multi-device form and the gloo rehearsal synchronise per step.
-    async_steps = mode == "single" or (dist_path and args.backend == "nccl")
+    # The single-process multi-device form does the same since round 4: pt_multi_render_device posts a frame to the devices'
+    # host threads and returns, and stream order keeps consecutive frames apart on every device (its send buffer is written
+    # by a resolve that follows the previous frame's gather in that device's stream; the root's receive buffer by a gather
+    # that follows the previous frame's row permutation).  Only the gloo rehearsal synchronises per step.
+    async_steps = mode in ("single", "multi") or (dist_path and args.backend == "nccl")
+    # one process per GPU over RCCL: the film resolve writes the gather's send buffer itself (pt_render_device_packed)
+    packed_dist = dist_path and args.backend == "nccl"
 
     def step(last):
-        ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
+        if packed_dist:
+            ctx.render_packed_into(cam, prm, film_gather.send.data_ptr())
+        else:
+            ctx.render_into(cam, prm, lin.data_ptr(), rgba.data_ptr())
         if not async_steps or last:
             ctx.sync()
-        if dist_path:
+        if packed_dist:
+            film_gather.start_prepacked()
+        elif dist_path:
             film_gather.start(lin.to(comm_dev), rgba.to(comm_dev))
         if not async_steps or last:
             st = ctx.stats()
@@ -314,11 +333,46 @@ def main(argv=None):
     else:
         job_samples = float(acc["samples"])     # pt_multi_get_stats sums over the devices
 
+    if world > 1:
+        # launch times for the roofline: three more steps with per-launch events, outside the timed region
+        prm.profile = 1
+        for key in ("vertices", "shadow_rays", "bounce_ms", "launches", "total_ms", "p_vertices", "p_ms", "p_launches"):
+            acc[key] = 0 if isinstance(acc[key], int) else 0.0
+        keep_samples = acc["samples"]
+        async_was, async_steps = async_steps, False
+        for k in range(3):
+            step(True)
+        if dist_path:
+            film_gather.finish()
+        async_steps = async_was
+        acc["samples"] = keep_samples // args.steps * 3
+        prm.profile = 0
+    multi_info = ctx.info() if mode == "multi" else None
+
+    host_buffers = None
+    if args.workload == "ref" and rank == 0 and world == 1:
+        # the same job through the one-shot entry with HOST buffers (scene upload, render, film over PCIe): what replaces
+        # main.rs:43-66 as it stands
+        pt.render_host(cam, objs, pt.default_params(spp=spp))                   # creates the cached context and its buffers
+        t1 = time.perf_counter()
+        reps = max(1, min(args.steps, 5))
+        for _ in range(reps):
+            h_lin, h_rgba = pt.render_host(cam, objs, pt.default_params(spp=spp))
+        dt = (time.perf_counter() - t1) / reps
+        assert (h_lin == lin.cpu().numpy()).all() and (h_rgba == rgba.cpu().numpy()).all()     # same film as the device-resident step
+        host_buffers = {"value": round(WIDTH * HEIGHT * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_render": round(dt * 1e3, 3),
+                        "what": "pt_render(): scene upload + render + both film planes copied to host memory (PCIe), blocking; "
+                                f"mean of {reps} calls; film bitwise equal to the device-resident step's"}
+
     if rank == 0:
         if dist_path:
             assert frame is not None and tuple(frame.shape) == (HEIGHT, WIDTH, 3) and torch.isfinite(frame).all()
             if world == 1:
-                assert torch.equal(frame, lin) and torch.equal(frame8, rgba)     # --force-dist: the gathered frame is the tile
+                # --force-dist: the gathered frame is the plain render of the tile
+                ref_lin = torch.empty_like(lin); ref_rgba = torch.empty_like(rgba)
+                ctx.render_into(cam, prm, ref_lin.data_ptr(), ref_rgba.data_ptr())
+                ctx.sync()
+                assert torch.equal(frame, ref_lin) and torch.equal(frame8, ref_rgba)
         else:
             assert torch.isfinite(lin).all()
         if mode == "multi" and world == 1:
@@ -351,7 +405,7 @@ def main(argv=None):
             kernel = "k_paths_bvh<MIS, OVF=false%s>" % (", DIFFUSE" if diffuse else "")
         elif len(objs) <= 128:
             # large batches over a scene in LDS: a regenerating form by default (pt_api.cpp; PtTuning.level0_form = 1: the queue form)
-            big = acc["samples"] / n_stat / max(p_launches, 1) > (1 << 22)
+            big = acc["samples"] / n_stat / max(p_launches, 1) > REGEN_MIN_PATHS
             n_mirror = sum(1 for o in objs if o.mat_tag == 2)
             if big and (args.level0_form == 3 or (args.level0_form == 0 and not diffuse and 0 < 2 * n_mirror <= len(objs))):
                 kernel = "k_paths_regen_split<MIS> (regenerating form, the Mirror vertices of a wave shaded in batches of 64)"
@@ -411,13 +465,14 @@ def main(argv=None):
             tiles = "whole image" + (" (through the single-process multi-device path: ncclCommInitAll over 1 device, ONE ncclGather, row "
                                      "permutation; frame checked bitwise against the plain render)" if mode == "multi" else "")
         elif mode == "multi":
-            tiles = (f"interleaved bands of {band_rows} rows over {world} devices driven by ONE process (pt_multi_*): ONE ncclGather "
-                     f"(RCCL, inside one ncclGroup) of the packed f32 + RGBA8 tiles to device 0 per step, then the row permutation there")
+            tiles = (f"interleaved bands of {band_rows} rows over {world} devices driven by ONE process (pt_multi_*, one host thread per "
+                     f"device): ONE ncclGather (RCCL) of the packed f32 + RGBA8 tiles to device 0 per step, then the row permutation there; "
+                     f"steps posted back to back")
         else:
             tiles = (f"interleaved bands of {band_rows} rows over {world} ranks, ONE {args.backend} gather of the packed f32 + RGBA8 "
                      f"frame to rank 0 per step, overlapped with the next step's rendering")
         out = {
-            "metric": ("Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2"
+            "metric": ("Msamples/sec (pixels x spp / s) at 1024^2/64spp" if args.workload == "c2" and not args.weak
                        else f"Msamples/sec (pixels x spp / s) at {WIDTH}x{HEIGHT}/{SPP}spp") +
                       ("" if args.accel == 0 else f", hit_scene = {'BVH' if args.accel == 1 else 'PT_ACCEL_AUTO'}"),
             "value": round(job_samples / elapsed / 1e6, 2),
@@ -442,6 +497,19 @@ def main(argv=None):
             },
             "roofline": roof,
         }
+        if multi_info is not None:
+            # proof that N ranks took part: the communicator's own count and the library version, plus what a frame costs the host
+            out["config"]["rccl"] = {"ncclCommCount": int(multi_info.comm_count), "version": int(multi_info.rccl_version),
+                                     "host_threads": int(multi_info.threaded) * world,
+                                     "enqueue_us_per_frame_slowest_device": round(multi_info.enqueue_us_max, 1),
+                                     "enqueue_us_per_frame_all_devices": round(multi_info.enqueue_us_sum, 1)}
+        elif dist_path:
+            out["config"]["rccl"] = {"world_size": dist.get_world_size(), "backend": args.backend,
+                                     "version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+        if world > 1:
+            roof["launch_times_from"] = "3 extra steps with per-launch HIP events after the timed region (the timed steps carry none)"
+        if host_buffers:
+            out["host_buffers"] = host_buffers
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pt, objs, WIDTH, HEIGHT, SPP, wl_desc.split(":")[0] + " scene")
         print(json.dumps(out), flush=True)

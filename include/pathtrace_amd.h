@@ -99,7 +99,9 @@ typedef struct {
      * for a render of >= 2^28 samples -- the 400 x 400 x 3000 default job included).  A host that shares the GPU
      * sets a smaller bound: the job is then cut into more sample batches, with the same film.                */
     uint64_t max_paths_in_flight;
-    uint32_t profile;        /* 1: time every path-kernel launch with HIP events */
+    uint32_t profile;        /* 1: time every path-kernel launch with HIP events (the launches of consecutive batches / renders
+                                then run strictly one after the other; otherwise one may start while its predecessor's last
+                                waves run dry) */
     /* Workgroups (256 threads) of the path kernel; every wave owns one private queue
      * segment.  0 = library default (about 1024 paths per wave).  Results do not
      * depend on it.                                                           */
@@ -226,6 +228,9 @@ int pt_render_device(PtContext* ctx, const PtCamera* cam, const PtRenderParams* 
 int pt_render_device_packed(PtContext* ctx, const PtCamera* cam, const PtRenderParams* params, void* d_packed);
 int pt_sync(PtContext* ctx);
 int pt_get_stats(PtContext* ctx, PtStats* out);
+/* Debug: the 16 raw 64-bit device-side counters behind PtStats as last collected ([0] shadow rays, [1] vertices, [2] deepest
+ * vertex, [3] level-0 vertices, [7] internal error flag, [8..] timing words of measurement builds, else 0).             */
+int pt_debug_raw_stats(PtContext* ctx, uint64_t* out16);
 
 /* Same render with HOST output buffers (blocking): device staging is owned by the
  * context, results are copied back over PCIe.  out_rgba8 may be NULL.          */

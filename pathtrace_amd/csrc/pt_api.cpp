@@ -75,13 +75,20 @@ constexpr uint32_t kContGrid = 1024;
 #ifndef PT_REGEN_EXPORT
 #define PT_REGEN_EXPORT 1
 #endif
-constexpr uint32_t kStatsWords = 16;            // 8 x u64 render statistics at the front of the counter buffer
+#ifndef PT_LANE_OVERLAP
+#define PT_LANE_OVERLAP 1
+#endif
+constexpr bool kLaneOverlap = PT_LANE_OVERLAP != 0;
+constexpr uint32_t kStatsWords = 32;            // 16 x u64 at the front of the counter buffer: 8 render statistics, 8 words for measurement builds (PT_DRAIN_TIMING)
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
 #ifndef PT_SPLIT_BY_DEFAULT
 #define PT_SPLIT_BY_DEFAULT 1
 #endif
 constexpr bool kSplitByDefault = PT_SPLIT_BY_DEFAULT != 0;   // scenes with a minority of Mirror objects: k_paths_regen_split (else the queue form)
-constexpr uint32_t kRegenStatic16 = 4;         // k_paths_regen: sixteenths of a batch's chunks dealt round-robin, the rest by the counters
+#ifndef PT_REGEN_STATIC16
+#define PT_REGEN_STATIC16 4
+#endif
+constexpr uint32_t kRegenStatic16 = PT_REGEN_STATIC16;   // k_paths_regen: sixteenths of a batch's chunks dealt round-robin, the rest by the counters
 constexpr uint32_t kRegenExportBelow = PT_REGEN_EXPORT;  // ... and its waves hand over once the batch is used up and fewer paths than this are alive
                                                // (1: they run dry themselves and no continuation launch follows)
 constexpr uint32_t kExportSmall = 64;          // a wave hands its segment over when fewer paths than this are left
@@ -151,6 +158,20 @@ struct PtContext {
     // multi-batch renders: the continuation launches and the film resolve of batch k run on side_stream while the
     // level-0 launch of batch k + 1 runs on the caller's stream (their own queue and a second sample buffer)
     hipStream_t side_stream = nullptr;
+    // regenerating launches: two LANES (stream + sample buffer + launch counters each) taken in turn by consecutive sample
+    // batches -- of one render or of renders enqueued back to back --, so that the launch of batch k + 1 fills the device
+    // while the last waves of batch k run dry; the resolves stay in order on the caller's stream
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t lane_done[2] = {nullptr, nullptr}, lane_begun[2] = {nullptr, nullptr}, ev_pre = nullptr;
+    bool lane_used[2] = {false, false};
+    // ... and THREE buffer sets (sample buffer + launch counters) taken in turn: a resolve cannot run beside a resident
+    // regenerating launch (it gets no wave slots until that launch runs dry: measured), so the resolve of batch k only
+    // runs while batch k + 1 drains -- and batch k + 2's launch, which starts at that moment too, must not wait for it
+    hipEvent_t set_free[3] = {nullptr, nullptr, nullptr};
+    bool set_used[3] = {false, false, false};
+    uint32_t set_next = 0;
+    DevBuf<ptk::Rgb> lsamp3;
+    uint32_t lane_next = 0;
     DevBuf<float4> cqueue[4];
     DevBuf<float4> caux, csray[2];    // ... and, for accel = 1, its own staged-pass scratch
     DevBuf<ptk::Rgb> lsamp2;
@@ -169,7 +190,7 @@ struct PtContext {
     // counters of batch parity 0, 1 are zero (the resolve of the batch that used them last cleared them) -- a render
     // then needs no memset in the stream
     bool stats_clean = false;
-    bool counters_clean[2] = {false, false};
+    bool counters_clean[3] = {false, false, false};
     uint32_t regen_occ[2][2][2] = {};          // cached occupancy query [exact_math][integrator][split] of this scene (0: not asked yet)
     uint32_t profiled_batches = 0;             // event slots (launch begin / end pairs) in use since the statistics were last collected
     std::vector<uint32_t> primary_events;      // slots of the level-0 launches
@@ -197,6 +218,19 @@ struct ListRender {
     uint32_t n = 0;
     const float4* inject[4] = {nullptr, nullptr, nullptr, nullptr};
 };
+
+// The lanes' streams are created with a priority other than the default: the runtime keeps a pool of hardware queues per
+// priority level and deals a level's streams over its pool, so the lanes then never share a hardware queue with a
+// default-priority stream -- the caller's, on which this library puts the resolves and its waits for the lanes.  (A wait
+// sitting in a shared hardware queue holds back whatever another stream put behind it there, e.g. the next lane launch.)
+#ifndef PT_LANE_PRIORITY
+#define PT_LANE_PRIORITY 1        // 1: the lowest priority the device offers (resolves go first), -1: the highest, 0: default
+#endif
+int lane_priority() {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 0;
+    return PT_LANE_PRIORITY > 0 ? least : PT_LANE_PRIORITY < 0 ? greatest : 0;
+}
 
 int ensure_events(PtContext* c, size_t n) {
     while (c->ev_pool.size() < n) {
@@ -341,11 +375,23 @@ int pt_context_create(int device, PtContext** out) {
     }
     for (int k = 0; k < 2; ++k)
         if (hipEventCreateWithFlags(&c->ev_l0[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_resolved[k], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ev_resolved[k], hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->lane_stream[k], hipStreamNonBlocking, lane_priority()) != hipSuccess ||
+            hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->lane_begun[k], hipEventDisableTiming) != hipSuccess) {
             delete c;
             return fail(PT_ERR_HIP, "hipEventCreate failed");
         }
-    if (hipHostMalloc((void**)&c->h_dstats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+    for (int k = 0; k < 3; ++k)
+        if (hipEventCreateWithFlags(&c->set_free[k], hipEventDisableTiming) != hipSuccess) {
+            delete c;
+            return fail(PT_ERR_HIP, "hipEventCreate failed");
+        }
+    if (hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "hipEventCreate failed");
+    }
+    if (hipHostMalloc((void**)&c->h_dstats, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_ovf, 4 * sizeof(uint32_t)) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
         delete c;
@@ -360,6 +406,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    for (int k = 0; k < 2; ++k) if (c->lane_stream[k]) (void)hipStreamSynchronize(c->lane_stream[k]);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release(); c->bvh_lead.release();
     c->bvh_aux.release(); c->bvh_sray[0].release(); c->bvh_sray[1].release();
@@ -367,12 +414,21 @@ int pt_context_destroy(PtContext* c) {
     for (auto& par : c->ovf) for (auto& q : par) for (auto& b : q) b.release();
     for (auto& b : c->cqueue) b.release();
     c->caux.release(); c->csray[0].release(); c->csray[1].release();
-    c->lsamp2.release();
+    c->lsamp2.release(); c->lsamp3.release();
     for (int k = 0; k < 2; ++k) {
         if (c->ev_l0[k]) (void)hipEventDestroy(c->ev_l0[k]);
         if (c->ev_resolved[k]) (void)hipEventDestroy(c->ev_resolved[k]);
     }
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (c->lane_done[k]) (void)hipEventDestroy(c->lane_done[k]);
+        if (c->lane_begun[k]) (void)hipEventDestroy(c->lane_begun[k]);
+
+        if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
+    }
+    for (int k = 0; k < 3; ++k) if (c->set_free[k]) (void)hipEventDestroy(c->set_free[k]);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    c->xchg.release();
     c->ovf_count.release();
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     c->lsamp.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
@@ -659,6 +715,20 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // only the 23-VGPR resolve kernel beside it, which would fit: 8 590 against 10 780.)
     const uint32_t regen_export = split ? 1u : c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;   // the split form has no hand-over
     const bool overlap = n_batches > 1 && !regen;
+    // Regenerating launches whose waves run dry themselves take the two lanes in turn (PtContext): the launch of the next
+    // batch -- the next render's, when renders are enqueued back to back -- starts on the other lane's stream as soon as that
+    // lane's stream is free, i.e. while this batch's last waves are still running dry (the ~0.4 ms in which a launch holds the
+    // device half empty: one rank's share of C2 at 8 ranks 1.04 -> 0.95 ms per render, profiles/r04/).  Resolves stay on the
+    // caller's stream, in order.  Not while that stream is being captured into a graph: the capture takes the in-order form.
+    // Nor with profile = 1: launches that overlap cannot be timed one by one (an event pair around a launch would span its wait
+    // for wave slots too), so a profiled render keeps them in order.
+    bool lanes = false;
+    if (kLaneOverlap && regen && regen_export <= 1u && prm->profile == 0u) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        lanes = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
+    }
+    const bool two_sets = overlap || lanes;      // both parities of sample buffer / launch counters / hand-over queue in use
 
     int rc;
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
@@ -669,17 +739,18 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         return rc;
     // (sized by the grid the launch really takes: never more workgroups than the largest batch has chunks for)
     const uint32_t regen_launch_grid = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (regen && split && (rc = c->xchg.ensure((size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024)))   // + slack: a violated stack
-        return rc;                                                                                                         // invariant (reported) stays inside the buffer
+    const size_t xchg_lane = (size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024;   // + slack: a violated stack invariant (reported) stays inside the buffer
+    if (regen && split && (rc = c->xchg.ensure(xchg_lane * (lanes ? 2 : 1)))) return rc;                   // (one per lane: two launches may be in flight)
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
-    if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
+    if (two_sets && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
+    if (lanes && (rc = c->lsamp3.ensure(n_paths_max))) return rc;
     if (overlap && hand_off)
         for (int k = 0; k < 4; ++k)
             if ((rc = c->cqueue[k].ensure(q_slots_cont))) return rc;
     if (overlap && hand_off && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
                                               (rc = c->csray[1].ensure(q_slots_cont))))
         return rc;
-    if ((rc = c->ovf_count.ensure(kStatsWords + 2 * kCountStride))) return rc;   // [render statistics | counters of batch parity 0 | parity 1]
+    if ((rc = c->ovf_count.ensure(kStatsWords + 3 * kCountStride))) return rc;   // [render statistics | launch counters of buffer set 0 | 1 | 2]
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
             for (int k = 0; k < 4; ++k)
@@ -720,16 +791,21 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // (pt_sync), the launch counters by the resolve of the batch that used them last (ResolveArgs.zero_words).  Only a
     // fresh or re-allocated buffer, a new scene or a render that failed half-way leaves something to clear here.
     const uint32_t launch_words = hand_off ? (regen ? kCountStride : 1u) : 0u;
+    bool lanes_wait_pre = false;        // the lanes' launches of this call start behind what this call puts on the caller's stream first
     if (!accumulate) {
         if (!c->stats_clean) HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), st));
         c->stats_clean = false;
         HIP_TRY(hipEventRecord(c->ev_begin, st));
+        lanes_wait_pre = true;          // (the statistics' clearing -- here or at their collection -- is on that stream)
     }
-    for (int par = 0; par < (overlap ? 2 : 1); ++par)
+    for (int par = 0; par < (lanes ? 3 : two_sets ? 2 : 1); ++par)
         if (launch_words && !c->counters_clean[par]) {
             HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords + kCountStride * par, 0, kCountStride * sizeof(uint32_t), st));
             c->counters_clean[par] = true;
+            lanes_wait_pre = true;
         }
+    if (lanes && lanes_wait_pre) HIP_TRY(hipEventRecord(c->ev_pre, st));
+    bool lane_waited_pre[2] = {false, false};
     uint32_t launches = 0;
     const uint32_t ev0 = c->profiled_batches;      // first free event slot
     uint32_t primary_count = 0;
@@ -742,8 +818,13 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     for (uint32_t batch = 0; batch < n_batches; ++batch) {
         const uint32_t s0 = batch * nb_max;
         const uint32_t nb = std::min(nb_max, spp - s0);
-        const int par = overlap ? (int)(batch & 1u) : 0;          // buffers of this batch
-        ptk::Rgb* const lsamp_b = par ? c->lsamp2.p : c->lsamp.p;
+        int par = overlap ? (int)(batch & 1u) : 0;                // buffer set of this batch
+        int lane = 0;                                             // ... and, with lanes, the stream its launch goes to
+        if (lanes) {
+            par = (int)c->set_next; c->set_next = (c->set_next + 1u) % 3u;
+            lane = (int)c->lane_next; c->lane_next ^= 1u;
+        }
+        ptk::Rgb* const lsamp_b = par == 2 ? c->lsamp3.p : par ? c->lsamp2.p : c->lsamp.p;
         a.s_base = prm->spp_offset + s0;
         a.lsamp = lsamp_b;
         // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
@@ -755,6 +836,18 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         const uint32_t n_levels = hand_off && !(regen && regen_export <= 1u) ? 2u : 1u;
         for (uint32_t level = 0; level < n_levels; ++level) {
             hipStream_t ls = level == 0 ? st : side;
+            if (lanes) {
+                // this lane's stream: behind the resolve that read the lane's sample buffer last (two batches ago), and
+                // behind this call's fills on the caller's stream, if any -- not behind the caller's stream as such
+                ls = c->lane_stream[lane];
+                if (c->set_used[par]) HIP_TRY(hipStreamWaitEvent(ls, c->set_free[par], 0));      // (the resolve of three batches ago)
+                if (lanes_wait_pre && !lane_waited_pre[lane]) { HIP_TRY(hipStreamWaitEvent(ls, c->ev_pre, 0)); lane_waited_pre[lane] = true; }
+                // ... and not before the other lane's launch has been handed to the device: two launches that become
+                // ready at the same moment would share the device from the start and run dry together
+                if (c->lane_used[lane ^ 1]) HIP_TRY(hipStreamWaitEvent(ls, c->lane_begun[lane ^ 1], 0));
+                HIP_TRY(hipEventRecord(c->lane_begun[lane], ls));
+                c->lane_used[lane] = true;
+            }
             const bool own = overlap && level > 0;       // continuation launch of an overlapped batch: its own queue
             uint32_t g = grid;
             a.n_first = np * nb;
@@ -774,20 +867,24 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             a.sray1 = own ? c->csray[1].p : c->bvh_sray[1].p;
             for (int k = 0; k < 4; ++k) {
                 a.q.q[k] = own ? c->cqueue[k].p : c->queue[k].p;
-                a.ovf_out.q[k] = hand_off ? c->ovf[par][0][k].p : nullptr;
-                a.ovf_in.q[k] = inject ? const_cast<float4*>(list->inject[k]) : (hand_off ? c->ovf[par][0][k].p : nullptr);
+                // (with lanes nothing is ever handed over -- the waves run dry themselves --: the sets share one queue)
+                a.ovf_out.q[k] = hand_off ? c->ovf[lanes ? 0 : par][0][k].p : nullptr;
+                a.ovf_in.q[k] = inject ? const_cast<float4*>(list->inject[k]) : (hand_off ? c->ovf[lanes ? 0 : par][0][k].p : nullptr);
             }
             a.ovf_out_count = d_count;
+            a.debug_tag = (uint32_t)par;
             a.chunk_counter = nullptr;
             a.xchg = nullptr;
             if (level == 0 && regen) {
                 a.chunk_counter = d_count + ptk::kRegenCounterStride;
-                if (split) a.xchg = c->xchg.p;
+                if (split) a.xchg = c->xchg.p + (lanes && lane ? xchg_lane : 0);
                 a.export_below = regen_export;
                 g = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
                 // the first kRegenStatic16 / 16 of the chunks are dealt statically
                 const uint32_t nwr = g * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;
-                a.regen_static = (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
+                // (none with lanes: a workgroup of this launch that only finds room when the previous launch's last waves end
+                // would carry its dealt share as a serial tail)
+                a.regen_static = lanes ? 0u : (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
             }
             if (hand_off) c->counters_clean[par] = false;       // until this batch's resolve has cleared them again
             if (profile) {
@@ -803,6 +900,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             if (overlap && level == 0) {     // the tail of this batch (side stream) starts when its level-0 launch is through
                 HIP_TRY(hipEventRecord(c->ev_l0[par], st));
                 HIP_TRY(hipStreamWaitEvent(side, c->ev_l0[par], 0));
+            }
+            if (lanes) {                     // the resolve (caller's stream) starts when the lane's launch is through
+                HIP_TRY(hipEventRecord(c->lane_done[lane], ls));
+                HIP_TRY(hipStreamWaitEvent(st, c->lane_done[lane], 0));
             }
         }
         ptk::ResolveArgs r{};
@@ -821,6 +922,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         HIP_TRY(hipGetLastError());
         if (launch_words) c->counters_clean[par] = true;
         if (overlap) HIP_TRY(hipEventRecord(c->ev_resolved[par], side));
+        if (lanes) { HIP_TRY(hipEventRecord(c->set_free[par], st)); c->set_used[par] = true; }
     }
     if (overlap)        // the caller's stream is complete when the last resolve is (the side stream is in order)
         HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
@@ -862,7 +964,7 @@ int pt_sync(PtContext* c) {
     if (c->stats_pending) {
         // the device-side statistics of the renders since the last collection: read now (the stream is idle) and cleared
         // for the next ones, so that no render carries a copy or a fill of them in its stream
-        HIP_TRY(hipMemcpy(c->h_dstats, c->ovf_count.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->h_dstats, c->ovf_count.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         c->stats_clean = hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), c->stream) == hipSuccess;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.total_ms = ms;
@@ -885,6 +987,25 @@ int pt_sync(PtContext* c) {
     }
     return PT_OK;
 }
+
+// Debug: the 16 raw device-side statistics words as last collected (pt_sync / pt_get_stats).  [0] shadow rays [1] vertices
+// [2] deepest vertex [3] level-0 vertices [7] internal error flag; [8..12] only in a PT_DRAIN_TIMING measurement build.
+int pt_debug_raw_stats(PtContext* c, uint64_t* out16) {
+    if (!c || !out16) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (!c->h_dstats) return fail(PT_ERR_INVALID_ARG, "no statistics yet");
+    for (int k = 0; k < 16; ++k) out16[k] = c->h_dstats[k];
+    return PT_OK;
+}
+
+#ifdef PT_DRAIN_TIMING
+// measurement build only: the per-wave records k_paths_regen left in the hand-over queue (4 words per wave)
+int pt_debug_wave_dump(PtContext* c, uint32_t* out, uint32_t n_waves) {      // n_waves | lane << 31
+    const uint32_t plane = n_waves >> 30; n_waves &= 0x3FFFFFFFu;      // plane = buffer set of the launch (BounceArgs.debug_tag)
+    if (!c || !out || !c->ovf[0][0][plane].p || n_waves > c->ovf[0][0][plane].cap) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipMemcpy(out, c->ovf[0][0][plane].p, (size_t)n_waves * 16, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+#endif
 
 int pt_get_stats(PtContext* c, PtStats* out) {
     if (!c || !out) return fail(PT_ERR_INVALID_ARG, "null argument");

@@ -122,6 +122,7 @@ struct BounceArgs {
     uint32_t integrator;
     uint32_t bvh_refill, bvh_leaf;   // traverse_segment thresholds (lanes)
     uint32_t accel;           // 0: linear scan (the reference's hit_scene), 1: BVH traversal, same answers
+    uint32_t debug_tag;       // measurement builds (PT_DRAIN_TIMING): plane of ovf_out that receives the per-wave stamps
 };
 
 constexpr uint32_t kBlock = 256;

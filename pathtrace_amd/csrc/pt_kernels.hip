@@ -820,6 +820,12 @@ k_paths(BounceArgs a) {
 // Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 79 VGPRs
 // (6 waves per SIMD), the generic one 93 (5; reached only with PtTuning.level0_form = 2).
 constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
+#ifndef PT_RING_LAZY
+#define PT_RING_LAZY 0
+#endif
+#ifndef PT_DRAIN_PRIO
+#define PT_DRAIN_PRIO 0
+#endif
 // DIFFUSE = the material set the kernel is compiled for (kMatsDiffuse / kMatsNoMirror / kMatsAll); round 3 added the
 // middle one: a scene with OrenNayar but no Mirror surface (material.rs:166-296) takes this kernel too by default.
 template <bool MIS, int DIFFUSE>
@@ -846,10 +852,24 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
     uint32_t dmax = 0;                     // per lane: deepest vertex of the paths this lane finished
     PathState p = parked_state();
     bool alive = false;
+#ifdef PT_DRAIN_TIMING      // measurement build: when does the batch run out under the waves, when does the last wave end
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_exhausted = 0ull;
+#endif
 
     for (;;) {
+#ifdef PT_DRAIN_TIMING
+        if (exhausted && t_exhausted == 0ull) t_exhausted = wall_clock64();
+#endif
         // ---- keep at least one chunk of camera rays in the ring
+#if PT_RING_LAZY
+        // ... or rather: only what the lanes without a path ask for now.  The ring then holds 0 .. 63 entries between
+        // refills instead of 64 .. 127, and what it holds when the batch runs out is work the wave has to do alone
+        const uint32_t ring_want = (uint32_t)__popcll(__ballot(!alive));
+        while (!exhausted && pool_cnt < ring_want) {
+#else
         while (!exhausted && pool_cnt < 64u) {
+#endif
             uint32_t chunk;
             if (st_next < a.regen_static) {            // dealt round-robin, like pass 0 of k_paths
                 chunk = st_next; st_next += nw;
@@ -881,6 +901,14 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
             pool_cnt += valid;
         }
         __builtin_amdgcn_wave_barrier();
+#if PT_DRAIN_PRIO
+        // end of the batch: the waves with the most work left go first (they end the launch)
+        if (exhausted) {
+            if (pool_cnt >= 32u) __builtin_amdgcn_s_setprio(3);
+            else if (pool_cnt != 0u) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+        }
+#endif
         // ---- lanes without a path take the ring's next entries, in lane order
         {
             const unsigned long long need = __ballot(!alive);
@@ -959,6 +987,15 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
+#ifdef PT_DRAIN_TIMING      // stats[8..12] (beyond the 8 words the host reads): ~begin (min), ~exhausted (min), exhausted (max), end (max), sum of per-wave drain times
+        const unsigned long long t_end = wall_clock64();
+        if (t_exhausted == 0ull) t_exhausted = t_end;
+        atomicMax(&a.stats[8], ~t_begin); atomicMax(&a.stats[9], ~t_exhausted); atomicMax(&a.stats[10], t_exhausted);
+        atomicMax(&a.stats[11], t_end); atomicAdd(&a.stats[12], t_end - t_exhausted);
+        // per wave: (begin, out of work, end) stamps and the vertices it processed, into the (unused) hand-over queue
+        if (a.ovf_out.q[0]) a.ovf_out.q[a.debug_tag & 3u][wave] = make_float4(__uint_as_float((uint32_t)t_begin), __uint_as_float((uint32_t)t_exhausted),
+                                                               __uint_as_float((uint32_t)t_end), __uint_as_float(wave_vertices));
+#endif
     }
 }
 
@@ -1640,6 +1677,10 @@ namespace PTK_IMPL {
 // nb samples of the batch are added in sample order into an f64 sum, so the film
 // does not depend on how paths were scheduled.
 __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
+    // A resolve usually runs BESIDE the next batch's path-kernel launch (pt_api.cpp, lanes), whose six older waves per SIMD
+    // keep the issue ports: as a seventh, youngest wave it was served last and took ~1 ms instead of 22 us (measured,
+    // tools/r04/).  Its few instructions go first instead.
+    __builtin_amdgcn_s_setprio(3);
     if (blockIdx.x == 0u && a.zero_words)
         for (uint32_t k = threadIdx.x; k < a.n_zero; k += kBlock) a.zero_words[k] = 0u;
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;

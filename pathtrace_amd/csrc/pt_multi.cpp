@@ -163,6 +163,17 @@ int multi_drain(PtMulti* m) {
     return PT_OK;
 }
 
+// Every posted frame is enqueued and complete -- WITHOUT collecting the statistics (pt_sync does that: a re-allocation between
+// two frames must not cut the sums a caller reads after the last one)
+int multi_quiesce(PtMulti* m) {
+    int rc = multi_drain(m);
+    for (size_t g = 0; g < m->ctx.size(); ++g) {
+        if (hipSetDevice(m->devices[g]) != hipSuccess || hipStreamSynchronize(pt_internal_stream(m->ctx[g])) != hipSuccess)
+            if (!rc) rc = pt_internal_fail(PT_ERR_HIP, "multi-GPU: synchronising device %d failed", m->devices[g]);
+    }
+    return rc;
+}
+
 // Device g's share of frame `frame`: the render into its send buffer and its part of the gather.  Runs on g's feeder thread
 // (or on the caller's).  defer_gather: the caller issues the n ncclGather calls itself, inside one group.
 int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderParams& prm, const FrameShape& fs, uint64_t frame,
@@ -171,7 +182,9 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
     PtRenderParams p = prm;
     p.band_rows = fs.band_rows; p.band_index = g; p.band_count = fs.n;
     const int rc = pt_render_device_packed(m->ctx[g], &cam, &p, m->packed[g].p);      // an empty tile renders nothing
-    if (rc) return rc;
+    std::string render_err;
+    if (rc) render_err = pt_last_error();
+    // (a failed render still takes part in the gather below: the other devices' gather calls would wait for this one for ever)
     hipStream_t st = pt_internal_stream(m->ctx[g]);
     if (m->shared) {
         // emulated gather: the tile goes to its place in the receive buffer once the row permutation of the previous
@@ -190,6 +203,7 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
         // this device's call of THE gather (ncclGather, rccl.h:745): its communicator, its stream, its thread
         NCCL_TRY(g_rccl.Gather(m->packed[g].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], st));
     }
+    if (rc) return pt_internal_fail(rc, "%s", render_err.c_str());
     return PT_OK;
 }
 
@@ -392,7 +406,7 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
     bool grow = m->recv.cap < fs.tile_px * 16 * n;
     for (uint32_t g = 0; g < n; ++g) grow = grow || m->packed[g].cap < fs.tile_px * 16;
     if (grow) {
-        if ((rc = pt_multi_sync(m))) return rc;
+        if ((rc = multi_quiesce(m))) return rc;
         for (uint32_t g = 0; g < n; ++g)
             if ((rc = m->packed[g].ensure(fs.tile_px * 16))) return rc;
         if ((rc = m->recv.ensure(fs.tile_px * 16 * n))) return rc;
@@ -474,7 +488,7 @@ int pt_multi_render_host(PtMulti* m, const PtCamera* cam, const PtRenderParams* 
     const size_t px = (size_t)cam->width * cam->height;
     int rc;
     if (m->out_lin.cap < std::max<size_t>(px, 1) * 12 || (out_rgba && m->out_rgba.cap < std::max<size_t>(px, 1) * 4))
-        if ((rc = pt_multi_sync(m))) return rc;          // the staging buffers grow: not while a frame may still write them
+        if ((rc = multi_quiesce(m))) return rc;          // the staging buffers grow: not while a frame may still write them
     if ((rc = m->out_lin.ensure(std::max<size_t>(px, 1) * 3 * sizeof(float))) || (out_rgba && (rc = m->out_rgba.ensure(std::max<size_t>(px, 1) * 4)))) return rc;
     if ((rc = pt_multi_render_device(m, cam, prm, (float*)m->out_lin.p, out_rgba ? (uint8_t*)m->out_rgba.p : nullptr))) return rc;
     if ((rc = pt_multi_sync(m))) return rc;

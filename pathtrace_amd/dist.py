@@ -77,7 +77,10 @@ class FilmGather:
         self.band_rows = band_rows
         self.my_rows = len(rows[rank])
         self.max_rows = max(len(r) for r in rows)
-        self.send = torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device)
+        # two send tiles: with pre-packed renders (start_prepacked) the render of frame k + 1 writes one while the gather of
+        # frame k, running on the backend's stream, still reads the other
+        self._sends = [torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+        self._cur, self._pending_buf = 0, None
         self.recv = self.bufs = self.perm = None
         self._work, self._pending, self._last = None, False, (None, None)
         # world_size 1 needs no exchange; always_collective issues the gather anyway (bench.py --force-dist: the whole
@@ -92,6 +95,11 @@ class FilmGather:
                     perm[y] = g * self.max_rows + k
             self.perm = torch.tensor(perm, dtype=torch.int64).to(device)
 
+    @property
+    def send(self):
+        """The send tile the next frame goes into ([max_rows, W, 16] bytes)."""
+        return self._sends[self._cur]
+
     def start(self, lin, rgba):
         """Pack this rank's tile and launch the gather without waiting for it (async_op): the collective runs
         on the backend's own stream / thread while the caller renders the next frame.  A previous gather still in
@@ -99,8 +107,24 @@ class FilmGather:
         if self._work is not None or self._pending:
             self._last = self.finish()
         self._pack(lin, rgba)
+        self._pending_buf = self.send
         if self._collective:
             self._work = dist.gather(self.send, gather_list=self.bufs, dst=self.dst, group=self.group, async_op=True)
+        self._pending = True
+
+    def start_prepacked(self):
+        """start() for a tile that is already in self.send: Context.render_packed_into(cam, prm, self.send.data_ptr()) made the
+        film resolve write the 16 B/pixel records there (pt_render_device_packed), so no pack step runs.  The render must
+        have been enqueued on torch's current stream of the device, where the gather is ordered.  Afterwards self.send is
+        the OTHER tile: the caller may enqueue the next render into it at once -- this gather keeps reading the one it was
+        given, and by the time that one is written again (two frames on) the start of the frame in between has waited
+        for this gather."""
+        if self._work is not None or self._pending:
+            self._last = self.finish()
+        self._pending_buf = self.send
+        if self._collective:
+            self._work = dist.gather(self._pending_buf, gather_list=self.bufs, dst=self.dst, group=self.group, async_op=True)
+        self._cur ^= 1
         self._pending = True
 
     def finish(self):
@@ -115,7 +139,7 @@ class FilmGather:
         self._pending = False
         if self.rank != self.dst:
             return None, None
-        return self._unpack(self.recv.view(self.world * self.max_rows, self.width, 16) if self._collective else self.send)
+        return self._unpack(self.recv.view(self.world * self.max_rows, self.width, 16) if self._collective else self._pending_buf)
 
     def _pack(self, lin, rgba):
         """This rank's tile -> self.send (16 bytes per pixel)."""

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Copy what tools/profile_workload.sh <tag> left under gpurun_out/prof_<tag>/ into profiles/<round>/<tag>/ -- only the files of
 # the LAST run of each pass (gpurun merges every call's output into gpurun_out/, so older runs of the same tag pile up there).
-#   tools/store_profile.sh <tag> [round dir, default profiles/r03]
+#   tools/store_profile.sh <tag> [round dir, default profiles/r04]
 set -eu
 TAG=${1:?usage: tools/store_profile.sh <tag> [round dir]}
-DST=${2:-profiles/r03}
+DST=${2:-profiles/r04}
 case "$TAG" in */*|.*|"") echo "bad tag: $TAG" >&2; exit 2;; esac
 SRC="gpurun_out/prof_$TAG"
 [ -d "$SRC" ] || { echo "$SRC does not exist" >&2; exit 2; }
