@@ -231,6 +231,9 @@ int pt_get_stats(PtContext* ctx, PtStats* out);
 /* Debug: the 16 raw 64-bit device-side counters behind PtStats as last collected ([0] shadow rays, [1] vertices, [2] deepest
  * vertex, [3] level-0 vertices, [7] internal error flag, [8..] timing words of measurement builds, else 0).             */
 int pt_debug_raw_stats(PtContext* ctx, uint64_t* out16);
+/* Debug: the entries one linear scan of the uploaded scene tests: spheres, single triangles, and triangle PAIRS (two consecutive
+ * triangles with the same first vertex and plane normal, e.g. the halves of a wall of World::new(), are tested together).     */
+int pt_debug_scan_layout(PtContext* ctx, uint32_t* n_spheres, uint32_t* n_triangles, uint32_t* n_pairs);
 
 /* Same render with HOST output buffers (blocking): device staging is owned by the
  * context, results are copied back over PCIe.  out_rgba8 may be NULL.          */

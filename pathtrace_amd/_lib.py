@@ -117,6 +117,7 @@ SYMBOLS = {
     "pt_sync": (C.c_int, [C.c_void_p]),
     "pt_get_stats": (C.c_int, [C.c_void_p, _P(PtStats)]),
     "pt_debug_raw_stats": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "pt_debug_scan_layout": (C.c_int, [C.c_void_p, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
     "pt_render_host": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),
     "pt_render_progressive": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),

