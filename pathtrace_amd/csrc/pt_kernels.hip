@@ -901,13 +901,18 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
             pool_cnt += valid;
         }
         __builtin_amdgcn_wave_barrier();
-#if PT_DRAIN_PRIO
+#if PT_DRAIN_PRIO == 1
         // end of the batch: the waves with the most work left go first (they end the launch)
         if (exhausted) {
             if (pool_cnt >= 32u) __builtin_amdgcn_s_setprio(3);
             else if (pool_cnt != 0u) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(1);
         }
+#elif PT_DRAIN_PRIO == 2
+        // a wave with fresh work goes before a wave that runs dry (of this launch or of the previous one, beside which this
+        // launch starts: pt_api.cpp, lanes): an issue slot spent on 64 live lanes does more than one spent on a few
+        if (exhausted && pool_cnt == 0u) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
 #endif
         // ---- lanes without a path take the ring's next entries, in lane order
         {
@@ -1301,9 +1306,12 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
 #ifndef PT_BVH_POSTPONE
 #define PT_BVH_POSTPONE 1
 #endif
+// order: null, or the order in which the slots are handed out -- order[k].w holds (as bits) the slot of the k-th ray
+// (sort_segment below); results still land in out[slot].
 template <bool TMAX_IN_RAY, bool ANY>
 PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plane0, const float4* __restrict__ plane1,
-                             float4* __restrict__ out, uint32_t n, float t_min, uint32_t refill_below, uint32_t leaf_batch) {
+                             float4* __restrict__ out, uint32_t n, float t_min, uint32_t refill_below, uint32_t leaf_batch,
+                             const float4* order = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t* stk = sc.stack + threadIdx.x;
@@ -1327,8 +1335,9 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
         // ---- hand the next slots to the idle lanes, in lane order
         const unsigned long long idle = __ballot(!has);
         if (next < n && idle != 0ull) {
-            const uint32_t cand = next + (uint32_t)__popcll(idle & lt);
+            uint32_t cand = next + (uint32_t)__popcll(idle & lt);
             if (!has && cand < n) {
+                if (order) cand = __float_as_uint(order[cand].w);
                 const float4 r0 = plane0[cand], r1 = plane1[cand];
                 const float t_max = TMAX_IN_RAY ? r1.z : kInf;
                 if (!TMAX_IN_RAY || r1.w != 0.0f) {
@@ -1475,15 +1484,60 @@ PT_DEV void traverse_segment(const SceneRef& sc, const float4* __restrict__ plan
     }
 }
 
+// Rays that share a wave should look alike: the lanes of a wave take the segment's rays in handing-out
+// order, so that order is made one of similar rays -- a counting sort of the wave's segment by a 6-bit key, direction octant
+// (the order in which a traversal visits the children of a node) x octant of the origin about the scene's centre.  Two
+// passes over the ray planes: histogram in LDS, wave-wide exclusive prefix, then every slot takes the next position of its
+// bucket (LDS atomic; the order inside a bucket is whatever the atomics give -- results are written by slot and the film by
+// pixel, so nothing depends on it).  The order goes into the spare .w of the per-slot result records (aux), which the
+// traversal does not touch.  Slots without a ray (shadow stage) sort into the last bucket; the traversal skips them as before.
+#ifndef PT_BVH_SORT
+#define PT_BVH_SORT 0        // measured (round 4, C4 accel 1, ms per launch): no sort 48.1, closest-hit stage sorted 50.4, both stages 53.0 -- rejected, kept as a measurement variant (1: stage 1, 2: both)
+#endif
+template <bool TMAX_IN_RAY>
+PT_DEV void sort_segment(const SceneRef& sc, const float4* __restrict__ plane0, const float4* __restrict__ plane1, float4* __restrict__ aux,
+                         uint32_t n, uint32_t* hist) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const f3 ctr = mk(__builtin_fmaf(32767.5f, sc.bvh.grid_cell[0], sc.bvh.grid_min[0]), __builtin_fmaf(32767.5f, sc.bvh.grid_cell[1], sc.bvh.grid_min[1]),
+                      __builtin_fmaf(32767.5f, sc.bvh.grid_cell[2], sc.bvh.grid_min[2]));
+    auto key_of = [&](uint32_t s) -> uint32_t {
+        const float4 r0 = plane0[s], r1 = plane1[s];
+        if (TMAX_IN_RAY && r1.w == 0.0f) return 63u;
+        return (r0.w < 0.0f ? 1u : 0u) | (r1.x < 0.0f ? 2u : 0u) | (r1.y < 0.0f ? 4u : 0u) |
+               (r0.x > ctr.x ? 8u : 0u) | (r0.y > ctr.y ? 16u : 0u) | (r0.z > ctr.z ? 32u : 0u);
+    };
+    hist[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t s = lane; s < n; s += 64u) atomicAdd(&hist[key_of(s)], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // exclusive prefix over the 64 buckets, one bucket per lane
+    uint32_t v = hist[lane], incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += up; }
+    __builtin_amdgcn_wave_barrier();
+    hist[lane] = incl - v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t s = lane; s < n; s += 64u) {
+        const uint32_t pos = atomicAdd(&hist[key_of(s)], 1u);
+        aux[pos].w = __uint_as_float(s);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 #ifndef PT_BVH_WAVES
 #define PT_BVH_WAVES 5      // measured on C4: 4 -> 74.0 ms, 5 -> 70.2 ms, 6 (spills) -> 72.8 ms
 #endif
 template <bool MIS, bool OVF, bool DIFFUSE, bool LIST>
 __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a) {
     extern __shared__ float4 lds[];
+    __shared__ uint32_t s_hist[kBlock / 64][64];                 // sort_segment: bucket counters of each wave
     const SceneRef sc = stage_scene<kModeBvh>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint32_t* const hist = s_hist[threadIdx.x >> 6];
     const uint32_t nw = gridDim.x * (kBlock / 64);
     uint32_t n_first, seg_cap;
     launch_shape<OVF>(a, nw, n_first, seg_cap);
@@ -1523,7 +1577,10 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
     for (uint32_t pass = 0; n_in != 0u; ++pass) {
         const uint32_t n_iter = (n_in + 63u) >> 6;
         // ---- stage 1: closest hits (rendering.rs:41)
-        traverse_segment<false, false>(sc, q.q[0], q.q[1], aux, n_in, a.t_min, a.bvh_refill, a.bvh_leaf);
+        // (the camera rays of pass 0 of a level-0 launch are consecutive pixels already)
+        const bool sorted = PT_BVH_SORT && (OVF || pass != 0u) && n_in > 64u;
+        if (sorted) sort_segment<false>(sc, q.q[0], q.q[1], aux, n_in, hist);
+        traverse_segment<false, false>(sc, q.q[0], q.q[1], aux, n_in, a.t_min, a.bvh_refill, a.bvh_leaf, sorted ? aux : nullptr);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         if (MIS) {
             // ---- stage 2: light samples -> shadow rays (world.rs:251-267, rendering.rs:58-62)
@@ -1545,7 +1602,9 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             // ---- stage 3: visibility (rendering.rs:62-65)
-            traverse_segment<true, true>(sc, sr0, sr1, aux, n_in, a.t_min, a.bvh_refill, a.bvh_leaf);
+            const bool ssorted = PT_BVH_SORT >= 2 && n_in > 64u;
+            if (ssorted) sort_segment<true>(sc, sr0, sr1, aux, n_in, hist);
+            traverse_segment<true, true>(sc, sr0, sr1, aux, n_in, a.t_min, a.bvh_refill, a.bvh_leaf, ssorted ? aux : nullptr);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
         // ---- stage 4: shade and compact in place
