@@ -107,6 +107,7 @@ constexpr uint32_t kExportMinPaths = 1u << PT_EXPORT_MIN_LOG2;
 #endif
 constexpr uint32_t kRegenMinPaths = 1u << PT_REGEN_MIN_LOG2;
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
+constexpr uint32_t kMaxProfiledLaunches = 1u << 14;      // bound of the HIP-event pool (profile = 1) between two collections of the statistics
 // PT_ACCEL_AUTO: the BVH when the scene is larger than one LDS blob and spheres + 2.5 x triangles > 512 (C4-like
 // scenes: the tiled scan costs ~0.11 ms per sphere and 67 M samples -- a Moeller-Trumbore test 2.5x that --, the BVH
 // ~70 ms flat -> break-even near 600 sphere tests)
@@ -789,7 +790,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     a.bvh_refill = c->tuning.bvh_refill ? std::min(64u, c->tuning.bvh_refill) : ptk::kRefillBelow;
     a.bvh_leaf = c->tuning.bvh_leaf ? c->tuning.bvh_leaf : ptk::kLeafBatch;
 
-    const bool profile = prm->profile != 0;
+    // (a caller that pipelines profiled renders without ever collecting the statistics stops adding event pairs at kMaxProfiledLaunches:
+    // the launch times then cover the first that many launches)
+    const bool profile = prm->profile != 0 && c->profiled_batches + 2u * n_batches <= kMaxProfiledLaunches;
     // The device-side words are normally zero already: the statistics were cleared when they were last collected
     // (pt_sync), the launch counters by the resolve of the batch that used them last (ResolveArgs.zero_words).  Only a
     // fresh or re-allocated buffer, a new scene or a render that failed half-way leaves something to clear here.

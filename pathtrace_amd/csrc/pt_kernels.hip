@@ -1736,10 +1736,9 @@ namespace PTK_IMPL {
 // nb samples of the batch are added in sample order into an f64 sum, so the film
 // does not depend on how paths were scheduled.
 __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
-    // A resolve usually runs BESIDE the next batch's path-kernel launch (pt_api.cpp, lanes), whose six older waves per SIMD
-    // keep the issue ports: as a seventh, youngest wave it was served last and took ~1 ms instead of 22 us (measured,
-    // tools/r04/).  Its few instructions go first instead.
-    __builtin_amdgcn_s_setprio(3);
+    // (With lanes -- pt_api.cpp -- a resolve becomes ready while the NEXT batch's regenerating launch holds every wave slot of
+    // the device: it gets none until that launch runs dry (22 us of work took ~1 ms; a raised wave priority changes nothing,
+    // the workgroups are simply not placed).  Hence the three buffer sets there: nobody waits for the resolve.)
     if (blockIdx.x == 0u && a.zero_words)
         for (uint32_t k = threadIdx.x; k < a.n_zero; k += kBlock) a.zero_words[k] = 0u;
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;

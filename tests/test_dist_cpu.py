@@ -59,6 +59,30 @@ def _worker(rank, world, port, H, W, band_rows, out_path):
             assert torch.equal(gl, frame + float(k)) and torch.equal(g8, (frame8 + k).to(torch.uint8)), k
         else:
             assert gl is None and g8 is None
+    # the pre-packed form (bench.py over RCCL since round 4): the renderer's film resolve writes the 16 B/pixel records into
+    # fg.send itself (pt_render_device_packed) and start_prepacked() only launches the gather.  The send tile is double
+    # buffered: frame k + 1 is written into the other tile WHILE the gather of frame k is in flight -- here the next tile is
+    # filled before the previous frame is collected, and every frame must still come out whole.
+    fg2 = FilmGather(H, W, band_rows, rank, world, torch.device("cpu"))
+    n_rows = lin_t.shape[0]
+    def fill(k):
+        dst = fg2.send                                            # the tile the next frame goes into
+        dst[:n_rows, :, :12] = (lin_t + float(10 * k)).contiguous().reshape(-1).view(torch.uint8).reshape(n_rows, W, 12)
+        dst[:n_rows, :, 12:] = (rgba_t + 3 * k).to(torch.uint8)
+        return dst.data_ptr()
+    ptrs, got2 = [], []
+    ptrs.append(fill(0)); fg2.start_prepacked()
+    for k in range(1, 4):
+        ptrs.append(fill(k))                                      # written while gather k - 1 is still pending
+        fg2.start_prepacked()                                     # completes gather k - 1 first
+        got2.append(fg2._last); fg2._last = (None, None)
+    got2.append(fg2.finish())
+    assert ptrs[0] != ptrs[1] and ptrs[0] == ptrs[2] and ptrs[1] == ptrs[3]      # two tiles, taken in turn
+    for k, (gl, g8) in enumerate(got2):
+        if rank == 0:
+            assert torch.equal(gl, frame + float(10 * k)) and torch.equal(g8, (frame8 + 3 * k).to(torch.uint8)), k
+        else:
+            assert gl is None and g8 is None
     dist.barrier()
     if rank == 0:
         np.savez(out_path, lin=frame.numpy(), rgba=frame8.numpy())

@@ -408,6 +408,18 @@ def test_statistics_add_up_over_pipelined_renders(pt, gpu_ctx):
         assert getattr(st, name) == sum(getattr(s, name) for _, s in singles), name
     assert st.max_depth_reached == max(s.max_depth_reached for _, s in singles)
     assert st.primary_kernel_ms > 0 and abs(st.primary_kernel_ms - sum(s.primary_kernel_ms for _, s in singles)) < 0.5 * st.primary_kernel_ms
+    # an invalid call between two pipelined renders fails with its message and leaves their statistics alone
+    gpu_ctx.stats()
+    gpu_ctx.render_into(cam, prms[0], lin.data_ptr(), rgba.data_ptr())
+    with pytest.raises(pt._lib.PtError, match="spp"):
+        gpu_ctx.render_into(cam, pt.default_params(spp=0), lin.data_ptr(), rgba.data_ptr())
+    with pytest.raises(pt._lib.PtError, match="band_index"):
+        gpu_ctx.render_into(cam, pt.default_params(spp=1, band_index=3, band_count=2), lin.data_ptr(), rgba.data_ptr())
+    gpu_ctx.render_into(cam, prms[1], lin.data_ptr(), rgba.data_ptr())
+    st2 = gpu_ctx.stats()
+    for name in ("vertices", "shadow_rays", "samples", "bounce_launches", "batches"):
+        assert getattr(st2, name) == getattr(singles[0][1], name) + getattr(singles[1][1], name), name
+    assert torch.equal(lin, singles[1][0])
     # collected: the next render starts from zero again; so does a new scene
     lin2, _ = gpu_ctx.render(cam, prms[0])
     assert gpu_ctx.stats().vertices == singles[0][1].vertices
