@@ -202,6 +202,11 @@ def main(argv=None):
     ap.add_argument("--force-multi", action="store_true",
                     help="with --gpus 1: still run the single-process multi-device path (pt_multi_*: ncclCommInitAll, the "
                          "ncclGather, the row permutation) -- its rehearsal over real RCCL on a one-GPU box")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="REHEARSAL of the single-process form with --gpus N > 1 on a one-GPU box: N contexts on device 0, device-to-"
+                         "device copies where the real object calls ncclGather (pt_debug_multi_create_shared); everything else -- host "
+                         "threads, frames posted back to back, the packed resolve, the row permutation, this script's N > 1 branches -- "
+                         "is the real path.  The line it prints is marked as a rehearsal and is not a measurement of N GPUs")
     args = ap.parse_args(argv)
 
     mode, world, rank, local_rank = launch_mode(args.gpus, os.environ, args.force_dist, args.force_multi)
@@ -215,7 +220,9 @@ def main(argv=None):
     from pathtrace_amd.dist import FilmGather, default_band_rows
 
     args.gpus = world
-    if mode == "multi" and torch.cuda.device_count() < world:
+    if args.shared_device and mode != "multi":
+        raise SystemExit("--shared-device rehearses the single-process form: start it plainly with --gpus N")
+    if mode == "multi" and not args.shared_device and torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {world}: this host shows {torch.cuda.device_count()} GPU(s)")
     dev_index = local_rank if (mode != "dist" or args.backend == "nccl") else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
@@ -246,7 +253,7 @@ def main(argv=None):
     if mode == "multi":
         # ONE process, `world` devices: every device renders its interleaved bands, ONE ncclGather to device 0 (pt_multi.cpp)
         prm = pt.default_params(band_rows=band_rows, **common)
-        ctx = pt.Multi(list(range(world)))
+        ctx = pt.Multi(list(range(world)), shared_device=0 if args.shared_device else None)
         ctx.upload(objs)
         ctx.set_tuning(**tuning)
         rows = HEIGHT                           # the frame is assembled on device 0 by the library
@@ -308,7 +315,7 @@ def main(argv=None):
             dist.barrier()
 
     def device_sync():
-        for d in (range(world) if mode == "multi" else [dev_index]):
+        for d in (range(world) if mode == "multi" and not args.shared_device else [dev_index]):
             torch.cuda.synchronize(d)
 
     frame = frame8 = None
@@ -352,6 +359,7 @@ def main(argv=None):
         async_steps = async_was
         acc["samples"] = keep_samples // args.steps * 3
         prm.profile = 0
+    prof_steps = 3 if world > 1 else args.steps       # the steps acc's launch times and counters cover
     multi_info = ctx.info() if mode == "multi" else None
 
     host_buffers = None
@@ -448,7 +456,7 @@ def main(argv=None):
             "avg_launch_ms": round(avg_ms, 4),
             "launches": int(p_launches),
             "vertex_share": round(share, 4),
-            "all_path_kernels_ms_per_step": round(acc["bounce_ms"] / max(args.steps, 1), 4),
+            "all_path_kernels_ms_per_step": round(acc["bounce_ms"] / max(prof_steps, 1), 4),
             "traffic": None, "hbm_frac": None, "valu_issue_frac": None,
             "algorithmic_bytes_per_launch_unfused_pipeline": round(alg_bytes / max(p_launches, 1)),
         }
@@ -506,7 +514,9 @@ def main(argv=None):
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
                 "launch": {"single": "one process, one GPU", "multi": "one process, all GPUs (pt_multi_*)",
-                           "dist": "one process per GPU (torch.distributed)"}[mode],
+                           "dist": "one process per GPU (torch.distributed)"}[mode] +
+                          (f" -- REHEARSAL: {world} contexts on ONE device, copies in place of ncclGather; not a measurement of {world} GPUs"
+                           if args.shared_device else ""),
                 "tiles": tiles,
             },
             "roofline": roof,
