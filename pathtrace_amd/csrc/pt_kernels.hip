@@ -823,6 +823,10 @@ constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks
 #ifndef PT_RING_LAZY
 #define PT_RING_LAZY 0
 #endif
+#ifndef PT_DRAIN_MAIL
+#define PT_DRAIN_MAIL 0      // measured (round 4): N = 1 5.96 -> 6.17 ms (4 spilled dwords, the per-iteration checks), one rank's share at 8 ranks
+#endif                       // 0.955 -> 0.975 ms: pooling a workgroup's last paths in one wave buys nothing -- kept as a measurement variant
+constexpr uint32_t kMailT = 16;            // PT_DRAIN_MAIL: a wave with at most this many live paths at the end of the batch donates them
 #ifndef PT_DRAIN_PRIO
 #define PT_DRAIN_PRIO 0
 #endif
@@ -833,7 +837,16 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
     extern __shared__ float4 lds[];
     __shared__ float4 s_pool_d[kBlock / 64][kPool];      // (d.x, d.y, d.z, bits(tile_row << 16 | x))
     __shared__ uint32_t s_pool_s[kBlock / 64][kPool];    // s_local << 16 (depth 0)
-    const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);
+#if PT_DRAIN_MAIL
+    // End of the batch: a wave left with a handful of paths hands them to a sibling wave of its workgroup and ends (see the
+    // main loop).  One region per donor wave, plane-major; cnt = entries published, head = entries taken (atomic), active =
+    // waves of the workgroup that have neither ended nor donated.
+    __shared__ float4 s_mail[kBlock / 64][4][kMailT];
+    __shared__ uint32_t s_mail_cnt[kBlock / 64], s_mail_head[kBlock / 64], s_active;
+    if (threadIdx.x < kBlock / 64) { s_mail_cnt[threadIdx.x] = 0u; s_mail_head[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0u) s_active = kBlock / 64;
+#endif
+    const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);          // (its barrier also publishes the words above)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;
     float4* const pool_d = s_pool_d[wib];
@@ -852,6 +865,9 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
     uint32_t dmax = 0;                     // per lane: deepest vertex of the paths this lane finished
     PathState p = parked_state();
     bool alive = false;
+#if PT_DRAIN_MAIL
+    bool mail_spent = false;               // wave-uniform: this wave's mail region has been published once and withdrawn
+#endif
 #ifdef PT_DRAIN_TIMING      // measurement build: when does the batch run out under the waves, when does the last wave end
     const unsigned long long t_begin = wall_clock64();
     unsigned long long t_exhausted = 0ull;
@@ -935,7 +951,79 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
             pool_head += n_take; pool_cnt -= n_take;
         }
         __builtin_amdgcn_wave_barrier();
+#if PT_DRAIN_MAIL
+        // ---- end of the batch, nothing left in the ring: the workgroup's waves pool their last paths.
+        // A wave with at most kMailT live paths publishes them in its region and ends; a sibling with free lanes takes them.
+        // No wave ever waits: a donor publishes BEFORE it leaves the count of active waves, and every wave looks at the mail
+        // once more AFTER it has left that count (and comes back if there is some) -- so whichever of two leaves first, the
+        // other one sees either the mail or that it is the last wave, which keeps (takes back) its paths.
+        const bool mail_phase = a.export_below <= 1u && exhausted && pool_cnt == 0u;
+        if (mail_phase) {
+            const unsigned long long freem = __ballot(!alive);
+            uint32_t n_free = (uint32_t)__popcll(freem);
+            const uint32_t my_rank = lane_rank(freem);
+            uint32_t taken = 0;
+            for (uint32_t r = 0; r < kBlock / 64; ++r) {
+                if (r == wib || n_free == taken) continue;
+                const uint32_t cnt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_mail_cnt[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const uint32_t head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_mail_head[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (cnt <= head) continue;
+                const uint32_t want = cnt - head < n_free - taken ? cnt - head : n_free - taken;
+                uint32_t old = 0;
+                if (lane == 0u) old = __hip_atomic_fetch_add(&s_mail_head[r], want, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);
+                const uint32_t got = old < cnt ? (cnt - old < want ? cnt - old : want) : 0u;
+                if (!alive && my_rank >= taken && my_rank < taken + got) {
+                    const uint32_t e = old + (my_rank - taken);
+                    p = unpack_state(s_mail[r][0][e], s_mail[r][1][e], s_mail[r][2][e], s_mail[r][3][e]);
+                    alive = true;
+                }
+                taken += got;
+            }
+        }
+        uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+        // (a wave that once had to take its mail back -- mail_spent -- traces its paths to their end)
+        if (mail_phase && n_alive <= kMailT && !(mail_spent && n_alive != 0u)) {
+            if (n_alive != 0u) {                         // publish, then leave
+                const unsigned long long am = __ballot(alive);
+                if (alive) {
+                    const uint32_t e = lane_rank(am);
+                    s_mail[wib][0][e] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+                    s_mail[wib][1][e] = make_float4(p.d.y, p.d.z, __uint_as_float((p.yl << 16) | p.px), __uint_as_float((p.s_local << 16) | p.depth));
+                    s_mail[wib][2][e] = make_float4(p.beta.x, p.beta.y, p.beta.z, p.pdf_prev);
+                    s_mail[wib][3][e] = make_float4(p.L.x, p.L.y, p.L.z, p.eta_in);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0u) __hip_atomic_store(&s_mail_cnt[wib], n_alive, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            uint32_t prev = 0;
+            if (lane == 0u) prev = __hip_atomic_fetch_sub(&s_active, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            // mail of the others that nobody has taken yet?  (also after a donation: it must not be the last look anybody takes)
+            bool pending = false;
+            for (uint32_t r = 0; r < kBlock / 64; ++r)
+                if (r != wib) pending = pending || __hip_atomic_load(&s_mail_cnt[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >
+                                                       __hip_atomic_load(&s_mail_head[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pending = __builtin_amdgcn_readfirstlane(pending ? 1u : 0u) != 0u;
+            if (n_alive != 0u && prev > 1u && !pending) { alive = false; break; }      // donated: a sibling is (still) there to take them
+            if (n_alive == 0u && !pending) break;                                        // nothing left anywhere this wave could see
+            // stay: the last wave keeps its paths (takes its own mail back), or there is mail to take in the next iteration
+            if (lane == 0u) __hip_atomic_fetch_add(&s_active, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (n_alive != 0u) {
+                // un-publish what nobody took (a sibling may have taken some in the meantime: those lanes' paths are gone)
+                uint32_t old = 0;
+                if (lane == 0u) old = __hip_atomic_fetch_add(&s_mail_head[wib], n_alive, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);             // entries [0, old) were taken by siblings, [old, n_alive) come back
+                const unsigned long long am = __ballot(alive);
+                if (alive && lane_rank(am) < old) { alive = false; p.o = parked_origin(); p.d = parked_dir(); }
+                mail_spent = true;                       // the region is used up for good (cnt <= head from now on)
+            }
+            n_alive = (uint32_t)__popcll(__ballot(alive));
+            if (n_alive == 0u) continue;                 // only mail to fetch: next iteration
+        }
+#else
         const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+#endif
         // running dry (only once the batch is exhausted): hand the rest over
         if (n_alive < a.export_below) break;           // export_below >= 1: a wave without paths ends
 
