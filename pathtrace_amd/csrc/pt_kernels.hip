@@ -245,7 +245,7 @@ PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
     r.bvh = sc.bvh;
     r.stack = reinterpret_cast<uint32_t*>(lds);
     if (MODE == kModeLds) {
-        for (uint32_t k = threadIdx.x; k < sc.blob_f4; k += kBlock) lds[k] = sc.blob[k];
+        for (uint32_t k = threadIdx.x; k < sc.blob_f4; k += blockDim.x) lds[k] = sc.blob[k];      // (k_paths_regen runs smaller workgroups)
         __syncthreads();
         r.scan = lds;
         r.shape = lds + sc.scan_f4;
@@ -820,31 +820,41 @@ k_paths(BounceArgs a) {
 // Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 79 VGPRs
 // (6 waves per SIMD), the generic one 93 (5; reached only with PtTuning.level0_form = 2).
 constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
+// Workgroup size of k_paths_regen.  Its waves share nothing but the LDS copy of the scene, so a workgroup could be ONE wave --
+// a wave that ends would free a slot the next launch (pt_api.cpp, lanes) can take at once, where a four-wave workgroup needs
+// four slots of a CU at the same moment.  Measured (round 4, profiles/r04/ab_regen_block_64.txt): one rank's share of C2 at 8
+// ranks 0.94 -> 1.00 ms, the whole image unchanged: rejected, 256 stays; the knob remains for measurements.
+#ifndef PT_REGEN_BLOCK
+#define PT_REGEN_BLOCK 256
+#endif
+constexpr uint32_t kRegenBlock = PT_REGEN_BLOCK;
 #ifndef PT_RING_LAZY
 #define PT_RING_LAZY 0
 #endif
 #ifndef PT_DRAIN_MAIL
 #define PT_DRAIN_MAIL 0      // measured (round 4): N = 1 5.96 -> 6.17 ms (4 spilled dwords, the per-iteration checks), one rank's share at 8 ranks
 #endif                       // 0.955 -> 0.975 ms: pooling a workgroup's last paths in one wave buys nothing -- kept as a measurement variant
-constexpr uint32_t kMailT = 16;            // PT_DRAIN_MAIL: a wave with at most this many live paths at the end of the batch donates them
+#if PT_DRAIN_MAIL
+constexpr uint32_t kMailT = 16;            // a wave with at most this many live paths at the end of the batch donates them
+#endif
 #ifndef PT_DRAIN_PRIO
 #define PT_DRAIN_PRIO 0
 #endif
 // DIFFUSE = the material set the kernel is compiled for (kMatsDiffuse / kMatsNoMirror / kMatsAll); round 3 added the
 // middle one: a scene with OrenNayar but no Mirror surface (material.rs:166-296) takes this kernel too by default.
 template <bool MIS, int DIFFUSE>
-__global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesDiffuse : kRegenWavesGeneric) k_paths_regen(BounceArgs a) {
+__global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesDiffuse : kRegenWavesGeneric) k_paths_regen(BounceArgs a) {
     extern __shared__ float4 lds[];
-    __shared__ float4 s_pool_d[kBlock / 64][kPool];      // (d.x, d.y, d.z, bits(tile_row << 16 | x))
-    __shared__ uint32_t s_pool_s[kBlock / 64][kPool];    // s_local << 16 (depth 0)
+    __shared__ float4 s_pool_d[kRegenBlock / 64][kPool];      // (d.x, d.y, d.z, bits(tile_row << 16 | x))
+    __shared__ uint32_t s_pool_s[kRegenBlock / 64][kPool];    // s_local << 16 (depth 0)
 #if PT_DRAIN_MAIL
     // End of the batch: a wave left with a handful of paths hands them to a sibling wave of its workgroup and ends (see the
     // main loop).  One region per donor wave, plane-major; cnt = entries published, head = entries taken (atomic), active =
     // waves of the workgroup that have neither ended nor donated.
-    __shared__ float4 s_mail[kBlock / 64][4][kMailT];
-    __shared__ uint32_t s_mail_cnt[kBlock / 64], s_mail_head[kBlock / 64], s_active;
-    if (threadIdx.x < kBlock / 64) { s_mail_cnt[threadIdx.x] = 0u; s_mail_head[threadIdx.x] = 0u; }
-    if (threadIdx.x == 0u) s_active = kBlock / 64;
+    __shared__ float4 s_mail[kRegenBlock / 64][4][kMailT];
+    __shared__ uint32_t s_mail_cnt[kRegenBlock / 64], s_mail_head[kRegenBlock / 64], s_active;
+    if (threadIdx.x < kRegenBlock / 64) { s_mail_cnt[threadIdx.x] = 0u; s_mail_head[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0u) s_active = kRegenBlock / 64;
 #endif
     const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);          // (its barrier also publishes the words above)
     const uint32_t lane = threadIdx.x & 63u;
@@ -856,7 +866,7 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
     const uint32_t W = a.film_w;
     const f3 cam_o = mk(a.cam.origin[0], a.cam.origin[1], a.cam.origin[2]);
 
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + wib, nw = gridDim.x * (kBlock / 64);
+    const uint32_t wave = blockIdx.x * (kRegenBlock / 64) + wib, nw = gridDim.x * (kRegenBlock / 64);
     uint32_t st_next = wave;               // wave-uniform: next chunk of the static deal
     uint32_t ctr = blockIdx.x % kRegenCounters, ctr_dry = 0;   // wave-uniform: counter in use, counters found used up
     uint32_t pool_head = 0, pool_cnt = 0;  // wave-uniform: ring read position, entries
@@ -963,7 +973,7 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
             uint32_t n_free = (uint32_t)__popcll(freem);
             const uint32_t my_rank = lane_rank(freem);
             uint32_t taken = 0;
-            for (uint32_t r = 0; r < kBlock / 64; ++r) {
+            for (uint32_t r = 0; r < kRegenBlock / 64; ++r) {
                 if (r == wib || n_free == taken) continue;
                 const uint32_t cnt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_mail_cnt[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const uint32_t head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_mail_head[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1001,7 +1011,7 @@ __global__ void __launch_bounds__(kBlock, DIFFUSE == kMatsDiffuse ? kRegenWavesD
             prev = __builtin_amdgcn_readfirstlane(prev);
             // mail of the others that nobody has taken yet?  (also after a donation: it must not be the last look anybody takes)
             bool pending = false;
-            for (uint32_t r = 0; r < kBlock / 64; ++r)
+            for (uint32_t r = 0; r < kRegenBlock / 64; ++r)
                 if (r != wib) pending = pending || __hip_atomic_load(&s_mail_cnt[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >
                                                        __hip_atomic_load(&s_mail_head[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pending = __builtin_amdgcn_readfirstlane(pending ? 1u : 0u) != 0u;
@@ -1795,8 +1805,9 @@ static RegenKernel regen_kernel(const BounceArgs& a) {
 uint32_t PT_LAUNCH(regen_blocks_per_cu)(const BounceArgs& a) {
     int n = 0;
     const size_t lds = scene_lds_bytes(a.sc, kModeLds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_kernel(a), (int)kBlock, lds) != hipSuccess || n < 0) return 0u;
-    return (uint32_t)n;
+    const uint32_t block = a.xchg ? kBlock : kRegenBlock;        // (the form that batches Mirror vertices keeps four waves per workgroup)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_kernel(a), (int)block, lds) != hipSuccess || n < 0) return 0u;
+    return (uint32_t)n / (kBlock / block);                       // in units of four waves, like the grid the host passes
 }
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
     const int mode = scene_mode(a.sc, a.accel);
@@ -1809,7 +1820,8 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
         return;
     }
     if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen*)
-        hipLaunchKernelGGL(regen_kernel(a), dim3(grid), dim3(kBlock), lds, st, a);
+        const uint32_t block = a.xchg ? kBlock : kRegenBlock;    // grid = number of 4-wave units
+        hipLaunchKernelGGL(regen_kernel(a), dim3(grid * (kBlock / block)), dim3(block), lds, st, a);
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }
