@@ -95,7 +95,8 @@ typedef struct {
     /* Wavefront sizing: upper bound on paths resident in HBM at once (0 = library default).  It sizes the
      * context's device buffers, which persist between renders: the default is 2^26 paths (76 B of queue + 12 B of
      * sample buffer each, only as many as the job has) and 2^28 where the level-0 launch keeps its paths in
-     * registers (EVERY scene of <= 128 objects, whatever its materials: 12 B of sample buffer per path, i.e. up to 3.2 GB per context
+     * registers (EVERY scene of <= 128 objects, whatever its materials: 12 B of sample buffer per path, i.e. up to 3.2 GB per context --
+     * per buffer set: renders of several sample batches, or renders enqueued back to back, rotate through up to three of them --
      * for a render of >= 2^28 samples -- the 400 x 400 x 3000 default job included).  A host that shares the GPU
      * sets a smaller bound: the job is then cut into more sample batches, with the same film.                */
     uint64_t max_paths_in_flight;

@@ -746,8 +746,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const size_t xchg_lane = (size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024;   // + slack: a violated stack invariant (reported) stays inside the buffer
     if (regen && split && (rc = c->xchg.ensure(xchg_lane * (lanes ? 2 : 1)))) return rc;                   // (one per lane: two launches may be in flight)
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
-    if (two_sets && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
-    if (lanes && (rc = c->lsamp3.ensure(n_paths_max))) return rc;
+    if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
+    // (lanes: the second and third sample buffer are allocated when a batch first takes them -- a host that synchronises
+    // after every single-batch render only ever uses the first set, pt_sync restarts the rotation)
     if (overlap && hand_off)
         for (int k = 0; k < 4; ++k)
             if ((rc = c->cqueue[k].ensure(q_slots_cont))) return rc;
@@ -830,7 +831,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             par = (int)c->set_next; c->set_next = (c->set_next + 1u) % 3u;
             lane = (int)c->lane_next; c->lane_next ^= 1u;
         }
-        ptk::Rgb* const lsamp_b = par == 2 ? c->lsamp3.p : par ? c->lsamp2.p : c->lsamp.p;
+        DevBuf<ptk::Rgb>& lsamp_buf = par == 2 ? c->lsamp3 : par ? c->lsamp2 : c->lsamp;
+        if (lanes && (rc = lsamp_buf.ensure(n_paths_max))) return rc;
+        ptk::Rgb* const lsamp_b = lsamp_buf.p;
         a.s_base = prm->spp_offset + s0;
         a.lsamp = lsamp_b;
         // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
@@ -967,6 +970,7 @@ int pt_sync(PtContext* c) {
     if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->set_next = 0; c->lane_next = 0;       // everything enqueued so far is complete: the buffer sets and lanes start over
     if (c->stats_pending) {
         // the device-side statistics of the renders since the last collection: read now (the stream is idle) and cleared
         // for the next ones, so that no render carries a copy or a fill of them in its stream

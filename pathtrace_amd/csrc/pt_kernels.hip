@@ -1112,12 +1112,14 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
 //     turns out to hit a Mirror object (known after the closest-hit scan) does not shade it: it pushes the path -- the
 //     state BEFORE the vertex plus the scan's (id, t) -- onto the wave's SPECIAL stack and takes a new path like a lane
 //     whose path has ended.
-//   * when 64 Mirror vertices have piled up (or nothing else is left to do) the wave parks its 64 plain paths in memory,
-//     pops 64 special entries and runs ONE vertex for them with every lane on the GGX code (vertex_begin / scan / vertex_end
-//     of kMatsAll), then the closest-hit scan of their NEXT vertex: Mirror again (a path inside the sphere) -> back onto
-//     the special stack with its (id, t); anything else -> onto the wave's PLAIN stack, from which the regeneration step
-//     of the plain iterations takes entries before it takes camera rays.  Then the plain paths come back into the lanes.
-// Both stacks share one 128-entry region per wave in global memory (L2-resident: 14 KB per wave incl. the parking slots; the staging slots of a batch are in LDS), special growing up, plain growing down.  They cannot collide: paths enter a wave only through camera-ray
+//   * when 64 Mirror vertices have piled up (or nothing else is left to do) the wave parks its 64 plain paths in LDS (round 4;
+//     round 3: in global memory), pops 64 special entries -- whole, into the registers the parked paths left -- and runs ONE
+//     vertex for them with every lane on the GGX code (vertex_begin / scan / vertex_end of kMatsAll), then the closest-hit scan
+//     of their NEXT vertex, the survivors staying in registers: Mirror again (a path inside the sphere) -> back onto the special
+//     stack with its (id, t); anything else -> onto the wave's PLAIN stack, from which the regeneration step of the plain
+//     iterations takes entries before it takes camera rays.  Then the plain paths come back into the lanes.
+// Both stacks share one 128-entry region per wave in global memory (L2-resident: 10 KB per wave), special growing up, plain
+// growing down.  They cannot collide: paths enter a wave only through camera-ray
 // regeneration, which happens only when the plain stack is empty and (batches run whenever >= 64 specials wait) at most
 // 63 specials wait, so lanes + stacks never hold more than 127 paths.  No atomics, no other wave involved.
 // Same per-vertex functions on the same inputs as every other form (a path's arithmetic does not depend on which lane
@@ -1125,7 +1127,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
 constexpr int kWaitVm0 = 0x0F70;                                 // s_waitcnt vmcnt(0) alone (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 constexpr uint32_t kXq = 128;                                    // exchange entries per wave
 constexpr uint32_t kXqEntryF4 = 5;                               // stack entry: 4 float4 of path state (layout of Queue) + (bits(id), t, -, -)
-constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4 + 64u * 4u;   // the stacks + 64 parking slots of 4 float4
+constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4 + (PT_SPLIT_PARK_LDS ? 0u : 64u * 4u);   // the stacks (+ 64 parking slots of 4 float4 in the round-3 form)
 static_assert(kXqF4PerWave == kRegenSplitF4PerWave, "pt_kernels.h sizes the buffer");
 // One wave-uniform base pointer (two scalar registers); entry-major, so the planes of an entry are immediate offsets of
 // ONE address -- with plane-major arrays the compiler kept a scalar base per plane (24 SGPRs more than the kernel has).
@@ -1160,7 +1162,11 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     const uint32_t wib = threadIdx.x >> 6;
     float4* const pool_d = s_pool_d[wib];
     uint32_t* const pool_s = s_pool_s[wib];
+#if PT_SPLIT_PARK_LDS
+    float4 (*const park)[64] = s_stage[wib];             // the wave's plain paths while a batch of specials runs
+#else
     float4 (*const stage)[64] = s_stage[wib];
+#endif
     const uint32_t n_first = a.n_first;
     const uint32_t n_chunks = (n_first + 63u) >> 6;
     const uint32_t W = a.film_w;
@@ -1296,12 +1302,23 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
         // ---- batches of Mirror vertices: whenever a full wave of them waits, or nothing else is left to do
         auto plain_work = [&]() { return __ballot(alive) != 0ull || pool_cnt != 0u || !exhausted || pq_cnt != 0u; };
         if (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work())) {
+#if PT_SPLIT_PARK_LDS
+            // park the plain paths in LDS for the batch (round 4): their 16 registers carry the batch's paths instead -- the
+            // popped entry WHOLE (one wait per batch iteration instead of one for the ray part and one for the carry part), and
+            // the survivors across the scan of their next vertex (round 3 staged them in these LDS slots and parked the plain
+            // paths in global memory: 8 KB of stack traffic and three exposed round trips per batch more)
+            park[0][lane] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+            park[1][lane] = make_float4(p.d.y, p.d.z, __uint_as_float((p.yl << 16) | p.px), __uint_as_float((p.s_local << 16) | p.depth));
+            park[2][lane] = make_float4(p.beta.x, p.beta.y, p.beta.z, p.pdf_prev);
+            park[3][lane] = make_float4(p.L.x, p.L.y, p.L.z, p.eta_in);
+#else
             // park the plain paths: their 16 registers are free during the batch.  (The lane index goes through an empty
             // asm so that the compiler computes the parking / staging addresses here instead of hoisting twelve 64-bit
             // address pairs out of the path loop into registers it then has to spill.)
             uint32_t ln = lane;
             asm volatile("" : "+v"(ln));
             store_entry(x.park(ln), p);
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // entries pushed above are read by other lanes below
             do {
                 const uint32_t n = sq_cnt < 64u ? sq_cnt : 64u;
@@ -1311,7 +1328,11 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 int qid = -1; float qt = 0.0f;
                 if (qa) {
                     const float4* src = x.entry(e);
+#if PT_SPLIT_PARK_LDS
+                    q = unpack_state(src[0], src[1], src[2], src[3]);
+#else
                     unpack_ray(q, src[0], src[1]);
+#endif
                     const float4 it = src[4];
                     qid = __float_as_int(it.x); qt = it.y;
                 }
@@ -1333,22 +1354,26 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                         wave_shadow += (uint32_t)__popcll(sm);
                     }
                 }
+#if !PT_SPLIT_PARK_LDS
                 // the carry part only now (as k_paths does): eight registers less during the scans
                 asm volatile("" ::: "memory");
                 if (qa) { const float4* src = x.entry(e); unpack_carry(q, src[2], src[3]); }
+#endif
                 const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
                 if (qa && !qalive) {
                     a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
                     dmax = q.depth > dmax ? q.depth : dmax;
                 }
-                // the survivors' next vertex: Mirror again (a path inside the sphere) or not?  Their state waits in the
-                // staging slots meanwhile; the scan needs the ray only.
+                // the survivors' next vertex: Mirror again (a path inside the sphere) or not?
+#if !PT_SPLIT_PARK_LDS
+                // Their state waits in the staging slots meanwhile; the scan needs the ray only.
                 if (qalive) {
                     stage[0][lane] = make_float4(q.o.x, q.o.y, q.o.z, q.d.x);
                     stage[1][lane] = make_float4(q.d.y, q.d.z, __uint_as_float((q.yl << 16) | q.px), __uint_as_float((q.s_local << 16) | q.depth));
                     stage[2][lane] = make_float4(q.beta.x, q.beta.y, q.beta.z, q.pdf_prev);
                     stage[3][lane] = make_float4(q.L.x, q.L.y, q.L.z, q.eta_in);
                 }
+#endif
                 const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
                 asm volatile("" ::: "memory");
                 int id2; float t2;
@@ -1359,9 +1384,13 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const uint32_t n_p = (uint32_t)__popcll(m_p);
                 if (qalive) {
                     const uint32_t dst = spec2 ? sq_cnt + lane_rank(m_s) : kXq - pq_cnt - n_p + lane_rank(m_p);
-                    const float4 s0 = stage[0][lane], s1 = stage[1][lane], s2 = stage[2][lane], s3 = stage[3][lane];
                     float4* de = x.entry(dst);
+#if PT_SPLIT_PARK_LDS
+                    store_entry(de, q);
+#else
+                    const float4 s0 = stage[0][lane], s1 = stage[1][lane], s2 = stage[2][lane], s3 = stage[3][lane];
                     de[0] = s0; de[1] = s1; de[2] = s2; de[3] = s3;
+#endif
                     if (spec2) de[4] = make_float4(__int_as_float(id2), t2, 0.0f, 0.0f);
                 }
                 sq_cnt += (uint32_t)__popcll(m_s);
@@ -1369,9 +1398,13 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 overflow = overflow || sq_cnt + pq_cnt > kXq;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             } while (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work()));
+#if PT_SPLIT_PARK_LDS
+            p = unpack_state(park[0][lane], park[1][lane], park[2][lane], park[3][lane]);
+#else
             asm volatile("" : "+v"(ln));
             { const float4* pk = x.park(ln); p = unpack_state(pk[0], pk[1], pk[2], pk[3]); }
             __builtin_amdgcn_s_waitcnt(kWaitVm0);      // as above: no pending load may leave this branch
+#endif
         }
     }
 
