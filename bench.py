@@ -487,9 +487,9 @@ def main(argv=None):
             tiles = "whole image" + (" (through the single-process multi-device path: ncclCommInitAll over 1 device, ONE ncclGather, row "
                                      "permutation; frame checked bitwise against the plain render)" if mode == "multi" else "")
         elif mode == "multi":
-            tiles = (f"interleaved bands of {band_rows} rows over {world} devices driven by ONE process (pt_multi_*, one host thread per "
-                     f"device): ONE ncclGather (RCCL) of the packed f32 + RGBA8 tiles to device 0 per step, then the row permutation there; "
-                     f"steps posted back to back")
+            tiles = (f"interleaved bands of {band_rows} rows over {world} devices driven by ONE process (pt_multi_*): ONE ncclGather "
+                     f"(RCCL, the calls of the {world} devices inside one ncclGroup) of the packed f32 + RGBA8 tiles to device 0 per step, "
+                     f"then the row permutation there; steps posted back to back")
         else:
             tiles = (f"interleaved bands of {band_rows} rows over {world} ranks, ONE {args.backend} gather of the packed f32 + RGBA8 "
                      f"frame to rank 0 per step, overlapped with the next step's rendering")

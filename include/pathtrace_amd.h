@@ -265,12 +265,12 @@ void pt_shutdown(void);
  * path), and ONE RCCL gather (ncclGather, rccl.h:745) of the 16 B/pixel film tiles -- written by each device's film
  * resolve straight into its send buffer -- to the first device over xGMI.  The frame is bitwise independent of n.
  * RCCL is loaded with dlopen by pt_multi_create; hosts that render on one GPU never need it.
- * Host threads: with more than one device every device is fed by its own host thread (its render launches, its
- * ncclGather call on its own communicator), so the per-device enqueue costs overlap and pt_multi_render_device
- * returns as soon as the frame is posted; frames posted back to back are kept apart by stream order on every device.
- * An error of a posted frame is reported by the next pt_multi_sync / pt_multi_get_stats.  pt_multi_set_threads(m, 0)
- * selects the one-thread form instead (the caller's thread enqueues every device, the gather calls inside one
- * ncclGroupStart/End).  The object itself is not internally synchronised: call it from one thread at a time.        */
+ * pt_multi_render_device only enqueues and returns: frames posted back to back are kept apart by stream order on every
+ * device, and a device's share of a frame costs the host 13-14 us, so ONE host thread (the caller's; the n gather calls inside
+ * one ncclGroupStart/End) keeps eight devices fed.  pt_multi_set_threads(m, 1) gives every device its own host thread inside
+ * the library instead (its render launches, its ncclGather call on its own communicator): the call then returns as soon as the
+ * frame is posted, and an error of a posted frame is reported by the next pt_multi_sync / pt_multi_get_stats.  The object
+ * itself is not internally synchronised: call it from one thread at a time.                                          */
 typedef struct PtMulti PtMulti;
 int pt_multi_create(const int* devices, uint32_t n_devices, PtMulti** out);   /* contexts + ncclCommInitAll (rccl.h:236) + one 16-byte gather that connects the ranks */
 int pt_multi_destroy(PtMulti* m);

@@ -8,15 +8,14 @@
 // one ncclGather (rccl.h:745); the root then puts the gathered rows in image order.  The frame is bitwise independent
 // of the number of devices.
 //
-// Host side (round 4): every device has its own host thread (pt_feeder.h) that enqueues its share of a frame -- the
-// render, its ncclGather call (one communicator per thread, the standard one-thread-per-device use of RCCL), on the
-// root also the row permutation -- so the per-device enqueue times overlap instead of adding up, and
-// pt_multi_render_device returns as soon as the frame is posted: a caller may post frame k + 1 while the devices still
-// run frame k.  What keeps frames apart is stream order alone: on device g the send buffer of frame k + 1 is written by a
-// resolve that follows frame k's gather in g's stream, and on the root the receive buffer is written by a gather that
-// follows frame k's row permutation in the root's stream.  pt_multi_sync() waits for the threads, then for the streams.
-// pt_multi_set_threads(m, 0) restores the one-thread form (every device enqueued by the caller, the n ncclGather calls
-// inside one ncclGroupStart/End).
+// Host side (round 4): pt_multi_render_device only ENQUEUES -- per device the render, its ncclGather call, on the root the row
+// permutation -- and returns; a caller may post frame k + 1 while the devices still run frame k.  What keeps frames apart is
+// stream order alone: on device g the send buffer of frame k + 1 is written by a resolve that follows frame k's gather in g's
+// stream, and on the root the receive buffer is written by a gather that follows frame k's row permutation in the root's
+// stream.  By default the calling thread enqueues the devices in turn and the n gather calls form one ncclGroupStart/End;
+// pt_multi_set_threads(m, 1) gives every device its own host thread instead (pt_feeder.h: its launches, its ncclGather call
+// on its own communicator -- the one-thread-per-device use of RCCL), the call then returns as soon as the frame is posted
+// and pt_multi_sync() waits for the threads, then for the streams.
 //
 // RCCL is opened with dlopen the first time a multi-device object is created: a host that renders on one GPU never
 // needs the library, and a process that already holds an RCCL (torch) keeps using that one.
@@ -309,7 +308,10 @@ int pt_multi_create(const int* devices, uint32_t n, PtMulti** out) {
         };
         if ((rc = warm())) { pt_multi_destroy(m); return rc; }
     }
-    if (n > 1) m->feeder.reset(new ptfeed::Feeder(n));      // one device: nothing to overlap (pt_multi_set_threads(m, 1) for the rehearsal)
+    // Default: the calling thread enqueues every device in turn and the n gather calls form one ncclGroup -- the form RCCL's own
+    // tests run by default.  A device's share of a frame costs the host 13-14 us (tools/r04/multi_enqueue.py), so with frames
+    // posted back to back one thread keeps eight devices fed with room to spare; pt_multi_set_threads(m, 1) gives every device
+    // its own host thread (lowest latency of a single frame on many devices).
     *out = m;
     return PT_OK;
 }
@@ -332,7 +334,6 @@ int pt_debug_multi_create_shared(int device, uint32_t n, PtMulti** out) {
         return PT_OK;
     };
     if ((rc = events())) { pt_multi_destroy(m); return rc; }
-    if (n > 1) m->feeder.reset(new ptfeed::Feeder(n));
     *out = m;
     return PT_OK;
 }
