@@ -192,6 +192,7 @@ def main(argv=None):
     ap.add_argument("--export-below", type=int, default=0, help="PtTuning.export_below (0 = library default)")
     ap.add_argument("--level0-form", type=int, default=0, help="PtTuning.level0_form (0 = library default, 1 = queue form, 2 = regenerating form, 3 = regenerating form with batched Mirror vertices)")
     ap.add_argument("--regen-workgroups", type=int, default=0, help="PtTuning.regen_workgroups (0 = library default)")
+    ap.add_argument("--in-order", action="store_true", help="PtTuning.in_order = 1: no overlap of consecutive regenerating launches")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (64*N spp) instead of the strong-scaling default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
@@ -244,7 +245,7 @@ def main(argv=None):
     spp = SPP * world if args.weak else SPP
     band_rows = default_band_rows(HEIGHT, world) if mode != "single" else 0
     tuning = dict(cont_workgroups=args.cont_workgroups, export_below=args.export_below, level0_form=args.level0_form,
-                  regen_workgroups=args.regen_workgroups)
+                  regen_workgroups=args.regen_workgroups, in_order=1 if args.in_order else 0)
     # N = 1: every path-kernel launch of the timed steps is bracketed by HIP events (the roofline's launch time is measured
     # live in the timed region).  N > 1: a rank's share of a step is ~1 ms, so the timed steps carry no per-launch events;
     # the launch times for the roofline come from a few extra steps AFTER the timed region.

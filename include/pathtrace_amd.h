@@ -138,6 +138,8 @@ typedef struct {
                                 (k_paths_regen_split) if some but at most half of the objects are Mirror (the
                                 reference's own scene).  1: the queue form; 2: k_paths_regen; 3: k_paths_regen_split  */
     uint32_t regen_workgroups;/* workgroups of that regenerating launch (0: what the device holds at once)             */
+    uint32_t in_order;       /* 1: the regenerating launches of consecutive batches / renders run strictly one after the other (as
+                                with profile = 1); 0: the next one may start while the last waves of this one run dry            */
 } PtTuning;
 
 /* Counters of the renders enqueued on a context since they were last collected (pt_sync / pt_get_stats; pt_scene_upload

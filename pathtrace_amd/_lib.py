@@ -60,6 +60,7 @@ class PtTuning(C.Structure):
         ("cont_workgroups", C.c_uint32),
         ("level0_form", C.c_uint32),
         ("regen_workgroups", C.c_uint32),
+        ("in_order", C.c_uint32),
     ]
 
 

@@ -108,9 +108,9 @@ class Context:
             ptr = C.c_void_p(hip_stream_ptr if hip_stream_ptr else _lib.PT_STREAM_LEGACY_DEFAULT)
         check(lib().pt_context_set_stream(self._h, ptr))
 
-    def set_tuning(self, export_below=0, bvh_refill=0, bvh_leaf=0, cont_workgroups=0, level0_form=0, regen_workgroups=0):
+    def set_tuning(self, export_below=0, bvh_refill=0, bvh_leaf=0, cont_workgroups=0, level0_form=0, regen_workgroups=0, in_order=0):
         """Scheduling knobs (pt_context_set_tuning); 0 = library default.  Results never depend on them."""
-        t = _lib.PtTuning(export_below, bvh_refill, bvh_leaf, cont_workgroups, level0_form, regen_workgroups)
+        t = _lib.PtTuning(export_below, bvh_refill, bvh_leaf, cont_workgroups, level0_form, regen_workgroups, in_order)
         check(lib().pt_context_set_tuning(self._h, C.byref(t)))
 
     def render_into(self, cam, params, linear_ptr, rgba_ptr):
@@ -317,8 +317,8 @@ class Multi:
         self._objs = objs
         check(lib().pt_multi_scene_upload(self._h, objs, len(objs)))
 
-    def set_tuning(self, export_below=0, bvh_refill=0, bvh_leaf=0, cont_workgroups=0, level0_form=0, regen_workgroups=0):
-        t = _lib.PtTuning(export_below, bvh_refill, bvh_leaf, cont_workgroups, level0_form, regen_workgroups)
+    def set_tuning(self, export_below=0, bvh_refill=0, bvh_leaf=0, cont_workgroups=0, level0_form=0, regen_workgroups=0, in_order=0):
+        t = _lib.PtTuning(export_below, bvh_refill, bvh_leaf, cont_workgroups, level0_form, regen_workgroups, in_order)
         check(lib().pt_multi_set_tuning(self._h, C.byref(t)))
 
     def render_into(self, cam, params, linear_ptr, rgba_ptr):

@@ -727,7 +727,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // Nor with profile = 1: launches that overlap cannot be timed one by one (an event pair around a launch would span its wait
     // for wave slots too), so a profiled render keeps them in order.
     bool lanes = false;
-    if (kLaneOverlap && regen && regen_export <= 1u && prm->profile == 0u) {
+    if (kLaneOverlap && regen && regen_export <= 1u && prm->profile == 0u && c->tuning.in_order == 0u) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         lanes = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
         (void)hipGetLastError();

@@ -73,6 +73,7 @@ pub struct PtTuning {
     pub cont_workgroups: u32,
     pub level0_form: u32,
     pub regen_workgroups: u32,
+    pub in_order: u32,
 }
 
 #[repr(C)]

@@ -317,6 +317,23 @@ def test_tuning_knobs_do_not_change_the_film(pt, gpu_ctx):
             st = gpu_ctx.stats()
             assert torch_equal(lin, ref) and torch_equal(rgba, ref8)
             assert (st.vertices, st.shadow_rays) == (base.vertices, base.shadow_rays)
+        # launches of consecutive batches strictly in order (PtTuning.in_order) or overlapping (default): three batches each,
+        # and three renders enqueued back to back behind one synchronisation
+        import torch
+        small = pt.default_params(spp=8, max_paths_in_flight=3 * 1024 * 640)
+        for in_order in (1, 0):
+            gpu_ctx.set_tuning(in_order=in_order)
+            lin, rgba = gpu_ctx.render(cam, small)
+            st = gpu_ctx.stats()
+            assert torch_equal(lin, ref) and torch_equal(rgba, ref8) and st.batches == 3
+            assert (st.vertices, st.shadow_rays) == (base.vertices, base.shadow_rays)
+            outs = [(torch.zeros_like(ref), torch.zeros_like(ref8)) for _ in range(3)]
+            for lin_d, rgba_d in outs:
+                gpu_ctx.render_into(cam, prm, lin_d.data_ptr(), rgba_d.data_ptr())
+            gpu_ctx.sync()
+            for lin_d, rgba_d in outs:
+                assert torch_equal(lin_d, ref) and torch_equal(rgba_d, ref8)
+            assert gpu_ctx.stats().vertices == 3 * base.vertices
     finally:
         gpu_ctx.set_tuning()
 
