@@ -189,6 +189,23 @@ impl Multi {
         check(unsafe { sys::pt_multi_render_host(self.m, cam, params, film.linear_rgb.as_mut_ptr(), film.rgba8.as_mut_ptr()) })?;
         Ok(film)
     }
+    /// One host thread per device inside the library (`true`) or the calling thread for all of them, the gather calls in one
+    /// `ncclGroup` (`false`, the default): same frame either way.
+    pub fn set_threads(&mut self, enabled: bool) -> Result<(), Error> {
+        check(unsafe { sys::pt_multi_set_threads(self.m, enabled as i32) })
+    }
+    /// Devices, `ncclCommCount`, RCCL version, frames posted and what a frame costs the host.
+    pub fn info(&mut self) -> Result<sys::PtMultiInfo, Error> {
+        let mut i = sys::PtMultiInfo::default();
+        check(unsafe { sys::pt_multi_info(self.m, &mut i) })?;
+        Ok(i)
+    }
+    /// Counters of the frames since the last collection, summed over the devices.
+    pub fn stats(&mut self) -> Result<Stats, Error> {
+        let mut s = Stats::default();
+        check(unsafe { sys::pt_multi_get_stats(self.m, &mut s) })?;
+        Ok(s)
+    }
 }
 
 impl Drop for Multi {
