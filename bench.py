@@ -192,7 +192,9 @@ def main(argv=None):
     ap.add_argument("--export-below", type=int, default=0, help="PtTuning.export_below (0 = library default)")
     ap.add_argument("--level0-form", type=int, default=0, help="PtTuning.level0_form (0 = library default, 1 = queue form, 2 = regenerating form, 3 = regenerating form with batched Mirror vertices)")
     ap.add_argument("--regen-workgroups", type=int, default=0, help="PtTuning.regen_workgroups (0 = library default)")
-    ap.add_argument("--in-order", action="store_true", help="PtTuning.in_order = 1: no overlap of consecutive regenerating launches")
+    ap.add_argument("--in-order", action="store_true",
+                    help="round 3's method: PtTuning.in_order = 1 (consecutive launches never overlap) and HIP events around every launch of "
+                         "the timed steps; default: the timed steps overlap and the launch times come from 3 in-order steps after them")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (64*N spp) instead of the strong-scaling default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
@@ -246,10 +248,13 @@ def main(argv=None):
     band_rows = default_band_rows(HEIGHT, world) if mode != "single" else 0
     tuning = dict(cont_workgroups=args.cont_workgroups, export_below=args.export_below, level0_form=args.level0_form,
                   regen_workgroups=args.regen_workgroups, in_order=1 if args.in_order else 0)
-    # N = 1: every path-kernel launch of the timed steps is bracketed by HIP events (the roofline's launch time is measured
-    # live in the timed region).  N > 1: a rank's share of a step is ~1 ms, so the timed steps carry no per-launch events;
-    # the launch times for the roofline come from a few extra steps AFTER the timed region.
-    live_profile = 1 if world == 1 else 0
+    # The timed steps are enqueued back to back and carry NO per-launch events: the library then lets the launch of step k + 1 start
+    # while the last waves of step k run dry (lanes, pt_api.cpp), which is how a host that renders frame after frame uses it.  A
+    # launch that overlaps its neighbours has no duration of its own -- an event pair around it would span its wait for wave
+    # slots -- so the launch times for the `roofline` object come from a few extra steps AFTER the timed region, launched
+    # strictly one after the other with HIP events around every launch (PtRenderParams.profile = 1).  `--in-order` is round 3's
+    # method: every timed step in order and timed launch by launch (no overlap; `value` is then ~6 % lower on C2).
+    live_profile = 1 if args.in_order else 0
     common = dict(spp=spp, profile=live_profile, max_paths_in_flight=args.max_paths, workgroups=args.workgroups, accel=args.accel)
     if mode == "multi":
         # ONE process, `world` devices: every device renders its interleaved bands, ONE ncclGather to device 0 (pt_multi.cpp)
@@ -346,8 +351,9 @@ def main(argv=None):
     else:
         job_samples = float(acc["samples"])     # pt_multi_get_stats sums over the devices
 
-    if world > 1:
-        # launch times for the roofline: three more steps with per-launch events, outside the timed region
+    post_pass = not args.in_order
+    if post_pass:
+        # launch times for the roofline: three more steps, in order, with HIP events around every launch, outside the timed region
         prm.profile = 1
         for key in ("vertices", "shadow_rays", "bounce_ms", "launches", "total_ms", "p_vertices", "p_ms", "p_launches"):
             acc[key] = 0 if isinstance(acc[key], int) else 0.0
@@ -360,7 +366,7 @@ def main(argv=None):
         async_steps = async_was
         acc["samples"] = keep_samples // args.steps * 3
         prm.profile = 0
-    prof_steps = 3 if world > 1 else args.steps       # the steps acc's launch times and counters cover
+    prof_steps = 3 if post_pass else args.steps       # the steps acc's launch times and counters cover
     multi_info = ctx.info() if mode == "multi" else None
 
     host_buffers = None
@@ -531,8 +537,16 @@ def main(argv=None):
         elif dist_path:
             out["config"]["rccl"] = {"world_size": dist.get_world_size(), "backend": args.backend,
                                      "version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
-        if world > 1:
-            roof["launch_times_from"] = "3 extra steps with per-launch HIP events after the timed region (the timed steps carry none)"
+        if post_pass:
+            roof["launch_times_from"] = ("3 extra steps after the timed region, launched strictly in order with HIP events around every launch "
+                                         "(the timed steps are enqueued back to back without per-launch events: their launches overlap -- the next "
+                                         "one fills the device while the last waves of this one run dry -- and have no duration of their own)")
+            step_flops = alg_flops / 3.0                  # the level-0 launches of ONE step of this rank (single-process form: per device)
+            roof["frac_of_timed_step"] = round(step_flops / (elapsed / args.steps) / 1e12 / VALU_PEAK_TFLOPS, 4)
+            roof["frac_of_timed_step_note"] = ("algorithmic flops of this process's launches of one timed step / the step's wall time (resolve, "
+                                               "gather and everything else included) / peak: what the overlap buys, against `frac` of a launch on its own")
+        else:
+            roof["launch_times_from"] = "HIP events around every path-kernel launch of the timed steps (--in-order: launches strictly one after the other)"
         if host_buffers:
             out["host_buffers"] = host_buffers
         if world == 1 and not args.no_cpu_baseline:

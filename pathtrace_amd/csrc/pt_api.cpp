@@ -79,6 +79,14 @@ constexpr uint32_t kContGrid = 1024;
 #define PT_LANE_OVERLAP 1
 #endif
 constexpr bool kLaneOverlap = PT_LANE_OVERLAP != 0;
+#ifndef PT_LANES
+#define PT_LANES 3
+#endif
+#ifndef PT_LANE_GRID24
+#define PT_LANE_GRID24 11
+#endif
+constexpr uint32_t kLaneGrid24 = PT_LANE_GRID24;      // grid of a launch that shares the device with its neighbours, in 24ths of what the device holds
+constexpr int kLanes = PT_LANES;        // streams the regenerating launches of consecutive batches take in turn (2 or 3)
 constexpr uint32_t kStatsWords = 32;            // 16 x u64 at the front of the counter buffer: 8 render statistics, 8 words for measurement builds (PT_DRAIN_TIMING)
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
 #ifndef PT_SPLIT_BY_DEFAULT
@@ -152,7 +160,8 @@ struct PtContext {
     bool split_ok = false;            // a minority of the objects is Mirror: the regenerating form that batches their vertices pays
     uint32_t scan_counts[3] = {0, 0, 0};   // entries of the scan array by kind: spheres, single triangles, triangle pairs (pt_debug_scan_layout)
     // wavefront state
-    DevBuf<float4> xchg;              // k_paths_regen_split: exchange stacks + parking area of every wave
+    DevBuf<float4> xchg;              // k_paths_regen_split: exchange stacks of every wave, one region per lane
+    size_t xchg_stride = 0;           // float4 per lane region (grows only while every lane is idle)
     DevBuf<float4> queue[4];
     DevBuf<float4> bvh_aux, bvh_sray[2];   // accel = 1: per-slot scratch of the staged passes (k_paths_bvh)
     DevBuf<float4> ovf[2][2][4];      // overflow queues of the tail hand-off: per batch parity: leftover count, chunk counters (kCountStride)[plane]
@@ -163,9 +172,9 @@ struct PtContext {
     // regenerating launches: two LANES (stream + sample buffer + launch counters each) taken in turn by consecutive sample
     // batches -- of one render or of renders enqueued back to back --, so that the launch of batch k + 1 fills the device
     // while the last waves of batch k run dry; the resolves stay in order on the caller's stream
-    hipStream_t lane_stream[2] = {nullptr, nullptr};
-    hipEvent_t lane_done[2] = {nullptr, nullptr}, lane_begun[2] = {nullptr, nullptr}, ev_pre = nullptr;
-    bool lane_used[2] = {false, false};
+    hipStream_t lane_stream[kLanes] = {};
+    hipEvent_t lane_done[kLanes] = {}, lane_begun[kLanes] = {}, ev_pre = nullptr;
+    bool lane_used[kLanes] = {};
     // ... and THREE buffer sets (sample buffer + launch counters) taken in turn: a resolve cannot run beside a resident
     // regenerating launch (it gets no wave slots until that launch runs dry: measured), so the resolve of batch k only
     // runs while batch k + 1 drains -- and batch k + 2's launch, which starts at that moment too, must not wait for it
@@ -377,12 +386,16 @@ int pt_context_create(int device, PtContext** out) {
     }
     for (int k = 0; k < 2; ++k)
         if (hipEventCreateWithFlags(&c->ev_l0[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_resolved[k], hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithPriority(&c->lane_stream[k], hipStreamNonBlocking, lane_priority()) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_resolved[k], hipEventDisableTiming) != hipSuccess) {
+            delete c;
+            return fail(PT_ERR_HIP, "hipEventCreate failed");
+        }
+    for (int k = 0; k < kLanes; ++k)
+        if (hipStreamCreateWithPriority(&c->lane_stream[k], hipStreamNonBlocking, lane_priority()) != hipSuccess ||
             hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->lane_begun[k], hipEventDisableTiming) != hipSuccess) {
             delete c;
-            return fail(PT_ERR_HIP, "hipEventCreate failed");
+            return fail(PT_ERR_HIP, "lane stream / event creation failed");
         }
     for (int k = 0; k < 3; ++k)
         if (hipEventCreateWithFlags(&c->set_free[k], hipEventDisableTiming) != hipSuccess) {
@@ -408,7 +421,7 @@ int pt_context_destroy(PtContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
-    for (int k = 0; k < 2; ++k) if (c->lane_stream[k]) (void)hipStreamSynchronize(c->lane_stream[k]);
+    for (int k = 0; k < kLanes; ++k) if (c->lane_stream[k]) (void)hipStreamSynchronize(c->lane_stream[k]);
     c->scan.release(); c->shape.release(); c->mat.release(); c->blob.release(); c->runs.release(); c->lights.release();
     c->bvh_nodes.release(); c->bvh_rec.release(); c->bvh_ids.release(); c->bvh_lead.release();
     c->bvh_aux.release(); c->bvh_sray[0].release(); c->bvh_sray[1].release();
@@ -422,7 +435,7 @@ int pt_context_destroy(PtContext* c) {
         if (c->ev_resolved[k]) (void)hipEventDestroy(c->ev_resolved[k]);
     }
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kLanes; ++k) {
         if (c->lane_done[k]) (void)hipEventDestroy(c->lane_done[k]);
         if (c->lane_begun[k]) (void)hipEventDestroy(c->lane_begun[k]);
 
@@ -703,8 +716,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         if (occ == 0u) occ = prm->exact_math ? ptk::regen_blocks_per_cu_exact(q) : ptk::regen_blocks_per_cu_fast(q);
         if (occ != 0u) regen_per_cu = std::min(regen_per_cu, occ);
     }
-    const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups :
-                                c->n_cus * regen_per_cu);
+    const uint32_t regen_capacity = c->n_cus * regen_per_cu;          // workgroups the device holds at once
+    uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups : regen_capacity);
     const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
     const uint32_t nw_cont = cont_grid * kWavesPerBlock;
     // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup
@@ -732,6 +745,23 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         lanes = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
         (void)hipGetLastError();
     }
+    // With lanes a launch takes LESS than half of what the device holds (kLaneGrid24 / 24 of it): two consecutive launches are then
+    // resident side by side, a phase apart, and the third fills the slots the first frees while it runs dry -- the device never waits
+    // for one launch's last waves.  Measured (tools/r04/share_grid.py, C2, ms per render, 3 lanes): the whole image 6.01 with
+    // full-size launches, 5.69 at 704 of 1536 workgroups (5.82 at exactly half: no room for the third); one rank's share at 8
+    // ranks 0.95 -> 0.78.  A launch that runs alone (in order) takes the whole device as before.
+    // ... which needs three launches in flight: a render of three or more sample batches, or a caller that enqueues renders back
+    // to back (the previous launch has not completed when this one is enqueued).  A launch on its own -- a host that synchronises
+    // after every render -- still takes the whole device.
+    if (lanes && !prm->workgroups && !c->tuning.regen_workgroups) {
+        bool neighbours = n_batches >= 3;
+        if (!neighbours) {
+            const int last = (int)((c->lane_next + (uint32_t)kLanes - 1u) % (uint32_t)kLanes);       // lane of the most recent launch
+            neighbours = c->lane_used[last] && hipEventQuery(c->lane_done[last]) == hipErrorNotReady;
+            (void)hipGetLastError();
+        }
+        if (neighbours) regen_grid = std::max(1u, regen_capacity * kLaneGrid24 / 24u);
+    }
     const bool two_sets = overlap || lanes;      // both parities of sample buffer / launch counters / hand-over queue in use
 
     int rc;
@@ -743,8 +773,19 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         return rc;
     // (sized by the grid the launch really takes: never more workgroups than the largest batch has chunks for)
     const uint32_t regen_launch_grid = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
-    const size_t xchg_lane = (size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024;   // + slack: a violated stack invariant (reported) stays inside the buffer
-    if (regen && split && (rc = c->xchg.ensure(xchg_lane * (lanes ? 2 : 1)))) return rc;                   // (one per lane: two launches may be in flight)
+    // One region per lane (a launch may be in flight on each).  The lane stride is a property of the CONTEXT, not of this render:
+    // launches of earlier renders may still be using their regions, and the grid -- hence the memory a launch needs -- differs from
+    // render to render (whole device / a share of it, tuning).  It only ever grows, and only with every lane idle.
+    if (regen && split) {
+        const size_t need = (size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024;   // + slack: a violated stack invariant (reported) stays inside the buffer
+        if (need > c->xchg_stride) {
+            for (int k = 0; k < kLanes; ++k) HIP_TRY(hipStreamSynchronize(c->lane_stream[k]));
+            HIP_TRY(hipStreamSynchronize(st));
+            c->xchg_stride = need;
+        }
+        if ((rc = c->xchg.ensure(c->xchg_stride * kLanes))) return rc;
+    }
+    const size_t xchg_lane = c->xchg_stride;
     if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
     if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
     // (lanes: the second and third sample buffer are allocated when a batch first takes them -- a host that synchronises
@@ -812,7 +853,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             lanes_wait_pre = true;
         }
     if (lanes && lanes_wait_pre) HIP_TRY(hipEventRecord(c->ev_pre, st));
-    bool lane_waited_pre[2] = {false, false};
+    bool lane_waited_pre[kLanes] = {};
     uint32_t launches = 0;
     const uint32_t ev0 = c->profiled_batches;      // first free event slot
     uint32_t primary_count = 0;
@@ -829,7 +870,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         int lane = 0;                                             // ... and, with lanes, the stream its launch goes to
         if (lanes) {
             par = (int)c->set_next; c->set_next = (c->set_next + 1u) % 3u;
-            lane = (int)c->lane_next; c->lane_next ^= 1u;
+            lane = (int)c->lane_next; c->lane_next = (c->lane_next + 1u) % (uint32_t)kLanes;
         }
         DevBuf<ptk::Rgb>& lsamp_buf = par == 2 ? c->lsamp3 : par ? c->lsamp2 : c->lsamp;
         if (lanes && (rc = lsamp_buf.ensure(n_paths_max))) return rc;
@@ -853,7 +894,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 if (lanes_wait_pre && !lane_waited_pre[lane]) { HIP_TRY(hipStreamWaitEvent(ls, c->ev_pre, 0)); lane_waited_pre[lane] = true; }
                 // ... and not before the other lane's launch has been handed to the device: two launches that become
                 // ready at the same moment would share the device from the start and run dry together
-                if (c->lane_used[lane ^ 1]) HIP_TRY(hipStreamWaitEvent(ls, c->lane_begun[lane ^ 1], 0));
+                const int prev_lane = (lane + kLanes - 1) % kLanes;       // the lane of the launch before this one
+                if (c->lane_used[prev_lane]) HIP_TRY(hipStreamWaitEvent(ls, c->lane_begun[prev_lane], 0));
                 HIP_TRY(hipEventRecord(c->lane_begun[lane], ls));
                 c->lane_used[lane] = true;
             }
@@ -886,7 +928,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             a.xchg = nullptr;
             if (level == 0 && regen) {
                 a.chunk_counter = d_count + ptk::kRegenCounterStride;
-                if (split) a.xchg = c->xchg.p + (lanes && lane ? xchg_lane : 0);
+                if (split) a.xchg = c->xchg.p + (lanes ? (size_t)lane * xchg_lane : 0);
                 a.export_below = regen_export;
                 g = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
                 // the first kRegenStatic16 / 16 of the chunks are dealt statically

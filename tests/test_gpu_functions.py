@@ -338,6 +338,35 @@ def test_tuning_knobs_do_not_change_the_film(pt, gpu_ctx):
         gpu_ctx.set_tuning()
 
 
+def test_pipelined_renders_with_changing_launch_sizes_keep_their_exchange_memory_apart(pt, gpu_ctx):
+    """Renders enqueued back to back overlap their launches, and a launch that shares the device takes a smaller grid than one that
+    runs alone -- so consecutive launches of the reference scene (k_paths_regen_split, per-wave exchange stacks in global memory)
+    differ in size while several are in flight.  Each lane's region of that memory must not move under a launch that is still
+    running (round 4 had the lane stride follow the current render's grid: a memory fault in bench.py --workload c1).  Five
+    frames of 1024 x 1024 x 16 spp posted back to back -- the first alone on the device, the others sharing it, the last two with
+    a larger and a smaller tuned grid -- all equal the isolated render bit for bit, and no stack invariant is reported."""
+    import torch
+    gpu_ctx.upload(pt.builtin_scene(1))
+    cam = pt.camera_new(width=1024, height=1024)
+    prm = pt.default_params(spp=16)
+    ref, ref8 = gpu_ctx.render(cam, prm)
+    base = gpu_ctx.stats()
+    outs = [(torch.zeros_like(ref), torch.zeros_like(ref8)) for _ in range(5)]
+    try:
+        for k, (lin_d, rgba_d) in enumerate(outs):
+            if k == 3:
+                gpu_ctx.set_tuning(regen_workgroups=1900)
+            if k == 4:
+                gpu_ctx.set_tuning(regen_workgroups=300)
+            gpu_ctx.render_into(cam, prm, lin_d.data_ptr(), rgba_d.data_ptr())
+        gpu_ctx.sync()                                  # raises if a kernel reported a violated stack invariant
+        for k, (lin_d, rgba_d) in enumerate(outs):
+            assert torch_equal(lin_d, ref) and torch_equal(rgba_d, ref8), k
+        assert gpu_ctx.stats().vertices == 5 * base.vertices
+    finally:
+        gpu_ctx.set_tuning()
+
+
 def _oren_nayar_cornell(pt):
     """C2 with every Lambertian surface OrenNayar (material.rs:166-296), rough and smooth: a scene without Mirror
     surfaces, which takes the regenerating kernel compiled without the GGX code by default (round 3)."""

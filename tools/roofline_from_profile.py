@@ -22,8 +22,14 @@ if not dur:
     sys.exit("no kernel trace found")
 tot = {k: sum(x[1] for x in v) for k, v in dur.items()}
 dom = max(tot, key=tot.get)
-timed = [x[1] for x in sorted(dur[dom])][1:] or [x[1] for x in dur[dom]]      # drop the warm-up dispatch
+# bench.py's timed steps overlap their launches (the next one fills the device while the last waves of this one run dry): a
+# dispatch that waits for wave slots behind its predecessors has no duration of its own in the trace.  The launch time comes
+# from the dispatches that ran ALONE (bench.py's in-order steps after the timed region; every dispatch with --in-order).
+allv = sorted(dur[dom])
+alone = [x for i, x in enumerate(allv) if all(j == i or y[0] + y[1] <= x[0] or x[0] + x[1] <= y[0] for j, y in enumerate(allv))]
+timed = [x[1] for x in alone][(1 if len(alone) == len(allv) else 0):] or [x[1] for x in allv]      # all alone: drop the warm-up dispatch
 avg_ns = sum(timed) / len(timed)
+overlapped = [x for x in allv if x not in alone]
 
 # counters: per-dispatch average for the dominant kernel
 cnt = collections.defaultdict(float)
@@ -41,6 +47,10 @@ out = {
     "kernel": dom,
     "dispatches_timed": len(timed),
     "avg_launch_ms_kernel_trace": avg_ns / 1e6,
+    "avg_launch_note": "dispatches of the dominant kernel that overlap no other dispatch of it (in-order launches)",
+    "overlapping_dispatches": len(overlapped),
+    "overlapping_dispatches_period_ms": ((max(x[0] + x[1] for x in overlapped) - min(x[0] for x in overlapped)) / len(overlapped) / 1e6) if overlapped else None,
+    "overlapping_dispatches_avg_trace_duration_ms": (sum(x[1] for x in overlapped) / len(overlapped) / 1e6) if overlapped else None,
     "all_kernels_avg_ms": {k: sum(x[1] for x in v) / len(v) / 1e6 for k, v in dur.items()},
     "counters_per_launch": c,
     "source": f"rocprofv3 --kernel-trace --stats and one --pmc pass per run of `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline ...` (tools/profile_workload.sh {tag})",
