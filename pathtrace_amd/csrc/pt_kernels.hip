@@ -1840,7 +1840,7 @@ uint32_t PT_LAUNCH(regen_blocks_per_cu)(const BounceArgs& a) {
     const size_t lds = scene_lds_bytes(a.sc, kModeLds);
     const uint32_t block = a.xchg ? kBlock : kRegenBlock;        // (the form that batches Mirror vertices keeps four waves per workgroup)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_kernel(a), (int)block, lds) != hipSuccess || n < 0) return 0u;
-    return (uint32_t)n / (kBlock / block);                       // in units of four waves, like the grid the host passes
+    return (uint32_t)n * block / kBlock;                         // in units of four waves, like the grid the host passes
 }
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
     const int mode = scene_mode(a.sc, a.accel);
@@ -1854,7 +1854,7 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
     }
     if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen*)
         const uint32_t block = a.xchg ? kBlock : kRegenBlock;    // grid = number of 4-wave units
-        hipLaunchKernelGGL(regen_kernel(a), dim3(grid * (kBlock / block)), dim3(block), lds, st, a);
+        hipLaunchKernelGGL(regen_kernel(a), dim3(std::max(1u, grid * kBlock / block)), dim3(block), lds, st, a);
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }

@@ -9,10 +9,17 @@
 // of the number of devices.
 //
 // Host side (round 4): pt_multi_render_device only ENQUEUES -- per device the render, its ncclGather call, on the root the row
-// permutation -- and returns; a caller may post frame k + 1 while the devices still run frame k.  What keeps frames apart is
-// stream order alone: on device g the send buffer of frame k + 1 is written by a resolve that follows frame k's gather in g's
-// stream, and on the root the receive buffer is written by a gather that follows frame k's row permutation in the root's
-// stream.  By default the calling thread enqueues the devices in turn and the n gather calls form one ncclGroupStart/End;
+// permutation -- and returns; a caller may post frame k + 1 while the devices still run frame k.  Every device has two
+// streams: its context's (the render: regenerating launches on the context's lanes, the resolve that writes the send buffer)
+// and an EXCHANGE stream (its ncclGather call; on the root also the row permutation), and a ring of send buffers between them
+// (kSendSlots) -- frame k's resolve records `ready` for the exchange stream, its gather records `sent` for the resolve of
+// frame k + kSendSlots.  The gather is kept out of the render stream because its kernel can be LATE: with three launches of
+// a device in flight (pt_api.cpp: lanes) one regenerating dispatch is always waiting for wave slots, and while it waits the
+// dispatches of other queues queue up behind it -- RCCL's kernel (one workgroup, ~20 us of work) gets through when a launch
+// ENDS, up to a launch later (profiles/r04/reserved_cus_rejected.txt: not for want of free compute units).  In the render
+// stream that wait held back the next frame's resolve and with it the lanes (6.10 ms per C2 frame on one device against 5.77
+// without the gather); behind a ring of send buffers nobody waits for it.  On the root the receive buffer is written by a
+// gather that follows the previous frame's row permutation in the exchange stream.  By default the calling thread enqueues the devices in turn and the n gather calls form one ncclGroupStart/End;
 // pt_multi_set_threads(m, 1) gives every device its own host thread instead (pt_feeder.h: its launches, its ncclGather call
 // on its own communicator -- the one-thread-per-device use of RCCL), the call then returns as soon as the frame is posted
 // and pt_multi_sync() waits for the threads, then for the streams.
@@ -130,11 +137,24 @@ FrameShape frame_shape(const PtCamera* cam, const PtRenderParams* prm, uint32_t 
 
 }  // namespace
 
+// Send buffers per device.  The gather of a frame completes when the device next has room for its kernel, which with frames
+// posted back to back is when the ring is full and the lanes run out of work (pt_multi.cpp head): one such stall per
+// kSendSlots frames.  A frame uses fewer of them when kSendRingBytes would not hold that many of its tiles.
+#ifndef PT_SEND_SLOTS
+#define PT_SEND_SLOTS 8
+#endif
+constexpr uint32_t kSendSlots = PT_SEND_SLOTS;
+constexpr size_t kSendRingBytes = (size_t)1 << 30;
+
 struct PtMulti {
     std::vector<int> devices;
     std::vector<PtContext*> ctx;
     std::vector<ncclComm_t> comm;              // shared-device debug objects: none
-    std::vector<DevMem> packed;                // per device: the 16 B/pixel send buffer its film resolve writes
+    std::vector<DevMem> packed;                // per device: kSendSlots send buffers (16 B/pixel) its film resolves write in turn
+    std::vector<hipStream_t> xs;               // per device: the exchange stream (gather; on the root the row permutation)
+    std::vector<hipEvent_t> ev_ready, ev_sent; // per send buffer: written by the resolve / read by the gather
+    std::vector<uint8_t> slot_used;
+    uint32_t ring = kSendSlots;                // send buffers in use (<= kSendSlots: the frame size decides)
     DevMem recv, out_lin, out_rgba;            // root: gathered tiles; frame staging of the host entry
     std::unique_ptr<ptfeed::Feeder> feeder;    // one host thread per device; null: the caller's thread enqueues every device
     uint64_t frames = 0;                       // frames posted since creation
@@ -167,24 +187,39 @@ int multi_drain(PtMulti* m) {
 int multi_quiesce(PtMulti* m) {
     int rc = multi_drain(m);
     for (size_t g = 0; g < m->ctx.size(); ++g) {
-        if (hipSetDevice(m->devices[g]) != hipSuccess || hipStreamSynchronize(pt_internal_stream(m->ctx[g])) != hipSuccess)
+        if (hipSetDevice(m->devices[g]) != hipSuccess || hipStreamSynchronize(pt_internal_stream(m->ctx[g])) != hipSuccess ||
+            hipStreamSynchronize(m->xs[g]) != hipSuccess)
             if (!rc) rc = pt_internal_fail(PT_ERR_HIP, "multi-GPU: synchronising device %d failed", m->devices[g]);
     }
     return rc;
 }
+int sync_exchange(PtMulti* m) {
+    for (size_t g = 0; g < m->xs.size(); ++g) {
+        if (!m->xs[g]) continue;
+        HIP_TRY(hipSetDevice(m->devices[g]));
+        HIP_TRY(hipStreamSynchronize(m->xs[g]));
+    }
+    return PT_OK;
+}
 
-// Device g's share of frame `frame`: the render into its send buffer and its part of the gather.  Runs on g's feeder thread
-// (or on the caller's).  defer_gather: the caller issues the n ncclGather calls itself, inside one group.
+// Device g's share of frame `frame`: the render into the frame's send buffer and its part of the gather.  Runs on g's feeder
+// thread (or on the caller's).  defer_gather: the caller issues the n ncclGather calls itself, inside one group, and records
+// the `sent` events after it.
 int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderParams& prm, const FrameShape& fs, uint64_t frame,
                    bool defer_gather) {
     HIP_TRY(hipSetDevice(m->devices[g]));
     PtRenderParams p = prm;
     p.band_rows = fs.band_rows; p.band_index = g; p.band_count = fs.n;
-    const int rc = pt_render_device_packed(m->ctx[g], &cam, &p, m->packed[g].p);      // an empty tile renders nothing
+    const size_t slot = (size_t)g * kSendSlots + (size_t)((frame - 1) % m->ring);
+    hipStream_t st = pt_internal_stream(m->ctx[g]), xs = m->xs[g];
+    if (m->slot_used[slot]) HIP_TRY(hipStreamWaitEvent(st, m->ev_sent[slot], 0));     // the gather of frame - kSendSlots has read it
+    m->slot_used[slot] = 1;
+    const int rc = pt_render_device_packed(m->ctx[g], &cam, &p, m->packed[slot].p);   // an empty tile renders nothing
     std::string render_err;
     if (rc) render_err = pt_last_error();
     // (a failed render still takes part in the gather below: the other devices' gather calls would wait for this one for ever)
-    hipStream_t st = pt_internal_stream(m->ctx[g]);
+    HIP_TRY(hipEventRecord(m->ev_ready[slot], st));
+    HIP_TRY(hipStreamWaitEvent(xs, m->ev_ready[slot], 0));
     if (m->shared) {
         // emulated gather: the tile goes to its place in the receive buffer once the row permutation of the previous
         // frame has read it
@@ -192,24 +227,26 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
             std::unique_lock<std::mutex> lk(m->lat_mu);
             m->lat_cv.wait(lk, [&] { return m->unpacked_frame + 1 >= frame; });
             lk.unlock();
-            HIP_TRY(hipStreamWaitEvent(st, m->ev_unpacked, 0));
+            HIP_TRY(hipStreamWaitEvent(xs, m->ev_unpacked, 0));
         }
-        HIP_TRY(hipMemcpyAsync((char*)m->recv.p + (size_t)g * fs.tile_px * 16, m->packed[g].p, fs.tile_px * 16, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipEventRecord(m->ev_copied[g], st));
+        HIP_TRY(hipMemcpyAsync((char*)m->recv.p + (size_t)g * fs.tile_px * 16, m->packed[slot].p, fs.tile_px * 16, hipMemcpyDeviceToDevice, xs));
+        HIP_TRY(hipEventRecord(m->ev_copied[g], xs));
+        HIP_TRY(hipEventRecord(m->ev_sent[slot], xs));
         { std::lock_guard<std::mutex> lk(m->lat_mu); m->copied_frame[g] = frame; }
         m->lat_cv.notify_all();
     } else if (!defer_gather) {
-        // this device's call of THE gather (ncclGather, rccl.h:745): its communicator, its stream, its thread
-        NCCL_TRY(g_rccl.Gather(m->packed[g].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], st));
+        // this device's call of THE gather (ncclGather, rccl.h:745): its communicator, its exchange stream, its thread
+        NCCL_TRY(g_rccl.Gather(m->packed[slot].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], xs));
+        HIP_TRY(hipEventRecord(m->ev_sent[slot], xs));
     }
     if (rc) return pt_internal_fail(rc, "%s", render_err.c_str());
     return PT_OK;
 }
 
-// The root's tail of a frame: rows into image order, behind the gather in the root's stream
+// The root's tail of a frame: rows into image order, behind the gather in the root's exchange stream
 int enqueue_root_tail(PtMulti* m, const FrameShape& fs, uint64_t frame, float* d_linear, uint8_t* d_rgba) {
     HIP_TRY(hipSetDevice(m->devices[0]));
-    hipStream_t st = pt_internal_stream(m->ctx[0]);
+    hipStream_t st = m->xs[0];
     if (m->shared) {
         {
             std::unique_lock<std::mutex> lk(m->lat_mu);
@@ -231,13 +268,26 @@ int multi_alloc(uint32_t n, const int* devices, bool shared, PtMulti** out) {
     PtMulti* m = new PtMulti();
     m->devices.assign(devices, devices + n);
     m->ctx.assign(n, nullptr);
-    m->packed.resize(n);
+    m->packed.resize((size_t)n * kSendSlots);
+    m->xs.assign(n, nullptr);
+    m->ev_ready.assign((size_t)n * kSendSlots, nullptr);
+    m->ev_sent.assign((size_t)n * kSendSlots, nullptr);
+    m->slot_used.assign((size_t)n * kSendSlots, 0);
     m->enqueue_us.assign(n, 0.0);
     m->shared = shared;
     int rc;
+    auto streams = [&](uint32_t i) -> int {
+        HIP_TRY(hipSetDevice(devices[i]));
+        HIP_TRY(hipStreamCreateWithFlags(&m->xs[i], hipStreamNonBlocking));
+        for (uint32_t k = 0; k < kSendSlots; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_ready[(size_t)i * kSendSlots + k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_sent[(size_t)i * kSendSlots + k], hipEventDisableTiming));
+        }
+        return PT_OK;
+    };
     for (uint32_t i = 0; i < n; ++i) {
-        if ((rc = pt_context_create(devices[i], &m->ctx[i]))) { pt_multi_destroy(m); return rc; }
-        m->packed[i].device = devices[i];
+        if ((rc = pt_context_create(devices[i], &m->ctx[i])) || (rc = streams(i))) { pt_multi_destroy(m); return rc; }
+        for (uint32_t k = 0; k < kSendSlots; ++k) m->packed[(size_t)i * kSendSlots + k].device = devices[i];
     }
     m->recv.device = m->out_lin.device = m->out_rgba.device = devices[0];
     *out = m;
@@ -255,7 +305,16 @@ int pt_multi_destroy(PtMulti* m) {
     for (size_t i = 0; i < m->ctx.size(); ++i) {
         if (m->ctx[i]) (void)pt_sync(m->ctx[i]);
     }
+    (void)sync_exchange(m);
     for (ncclComm_t c : m->comm) if (c) (void)g_rccl.CommDestroy(c);
+    for (size_t i = 0; i < m->xs.size(); ++i) {
+        (void)hipSetDevice(m->devices[i]);
+        if (m->xs[i]) (void)hipStreamDestroy(m->xs[i]);
+        for (uint32_t k = 0; k < kSendSlots; ++k) {
+            if (m->ev_ready[i * kSendSlots + k]) (void)hipEventDestroy(m->ev_ready[i * kSendSlots + k]);
+            if (m->ev_sent[i * kSendSlots + k]) (void)hipEventDestroy(m->ev_sent[i * kSendSlots + k]);
+        }
+    }
     for (auto& b : m->packed) b.release();
     m->recv.release(); m->out_lin.release(); m->out_rgba.release();
     if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
@@ -289,20 +348,20 @@ int pt_multi_create(const int* devices, uint32_t n, PtMulti** out) {
         auto warm = [&]() -> int {
             int rc2;
             for (uint32_t g = 0; g < n; ++g) {
-                if ((rc2 = m->packed[g].ensure(16))) return rc2;
+                if ((rc2 = m->packed[(size_t)g * kSendSlots].ensure(16))) return rc2;
                 HIP_TRY(hipSetDevice(devices[g]));
-                HIP_TRY(hipMemsetAsync(m->packed[g].p, 0, 16, pt_internal_stream(m->ctx[g])));
+                HIP_TRY(hipMemsetAsync(m->packed[(size_t)g * kSendSlots].p, 0, 16, m->xs[g]));
             }
             if ((rc2 = m->recv.ensure(16 * (size_t)n))) return rc2;
             NCCL_TRY(g_rccl.GroupStart());
             for (uint32_t g = 0; g < n; ++g) {
-                const ncclResult_t rg = g_rccl.Gather(m->packed[g].p, m->recv.p, 16, ncclUint8, 0, m->comm[g], pt_internal_stream(m->ctx[g]));
+                const ncclResult_t rg = g_rccl.Gather(m->packed[(size_t)g * kSendSlots].p, m->recv.p, 16, ncclUint8, 0, m->comm[g], m->xs[g]);
                 if (rg != ncclSuccess) { (void)g_rccl.GroupEnd(); return pt_internal_fail(PT_ERR_HIP, "ncclGather (connection warm-up) failed on device %d: %s", devices[g], g_rccl.GetErrorString(rg)); }
             }
             NCCL_TRY(g_rccl.GroupEnd());
             for (uint32_t g = 0; g < n; ++g) {
                 HIP_TRY(hipSetDevice(devices[g]));
-                HIP_TRY(hipStreamSynchronize(pt_internal_stream(m->ctx[g])));
+                HIP_TRY(hipStreamSynchronize(m->xs[g]));
             }
             return PT_OK;
         };
@@ -394,7 +453,7 @@ int pt_multi_set_tuning(PtMulti* m, const PtTuning* t) {
 }
 
 // Post the whole frame: every device renders its bands, then the one gather, then the row permutation on the first
-// device, whose stream is complete when the frame is.  d_linear_rgb / d_rgba8: buffers on the FIRST device,
+// device; pt_multi_sync() completes it.  d_linear_rgb / d_rgba8: buffers on the FIRST device,
 // H*W*3 floats / H*W*4 bytes (d_rgba8 may be NULL).  params->band_rows = 0 picks about eight bands per device;
 // band_index / band_count of params are ignored (the object owns the partition).  With host threads the call returns
 // once the frame is posted to them; an error of a device's enqueue is reported by the next pt_multi_sync / _get_stats.
@@ -404,12 +463,16 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
     const FrameShape fs = frame_shape(cam, prm, n);
     int rc;
     // buffers: a larger frame than any before re-allocates -- not under the feet of frames still in flight
-    bool grow = m->recv.cap < fs.tile_px * 16 * n;
-    for (uint32_t g = 0; g < n; ++g) grow = grow || m->packed[g].cap < fs.tile_px * 16;
+    const uint32_t ring = (uint32_t)std::min<size_t>(kSendSlots, std::max<size_t>(2, kSendRingBytes / (fs.tile_px * 16)));
+    bool grow = m->recv.cap < fs.tile_px * 16 * n || ring != m->ring;
+    for (uint32_t g = 0; g < n; ++g)
+        for (uint32_t k = 0; k < ring; ++k) grow = grow || m->packed[(size_t)g * kSendSlots + k].cap < fs.tile_px * 16;
     if (grow) {
-        if ((rc = multi_quiesce(m))) return rc;
+        if ((rc = multi_quiesce(m))) return rc;          // (also when the ring changes length: slot numbers start afresh)
+        m->ring = ring;
         for (uint32_t g = 0; g < n; ++g)
-            if ((rc = m->packed[g].ensure(fs.tile_px * 16))) return rc;
+            for (uint32_t k = 0; k < ring; ++k)
+                if ((rc = m->packed[(size_t)g * kSendSlots + k].ensure(fs.tile_px * 16))) return rc;
         if ((rc = m->recv.ensure(fs.tile_px * 16 * n))) return rc;
     }
     const uint64_t frame = ++m->frames;
@@ -440,14 +503,19 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
         if ((rc = enqueue_device(m, g, cam_v, prm_v, fs, frame, true))) return rc;
         timed(g, t0);
     }
-    // 2. ONE gather of the padded tiles to the first device (ncclGather, rccl.h:745), every device on its own stream
+    // 2. ONE gather of the padded tiles to the first device (ncclGather, rccl.h:745), every device on its exchange stream
     if (!m->shared) {
+        const size_t k = (size_t)((frame - 1) % m->ring);
         NCCL_TRY(g_rccl.GroupStart());
         for (uint32_t g = 0; g < n; ++g) {
-            const ncclResult_t r = g_rccl.Gather(m->packed[g].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], pt_internal_stream(m->ctx[g]));
+            const ncclResult_t r = g_rccl.Gather(m->packed[(size_t)g * kSendSlots + k].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], m->xs[g]);
             if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return pt_internal_fail(PT_ERR_HIP, "ncclGather failed on device %d: %s", m->devices[g], g_rccl.GetErrorString(r)); }
         }
         NCCL_TRY(g_rccl.GroupEnd());
+        for (uint32_t g = 0; g < n; ++g) {
+            HIP_TRY(hipSetDevice(m->devices[g]));
+            HIP_TRY(hipEventRecord(m->ev_sent[(size_t)g * kSendSlots + k], m->xs[g]));
+        }
     }
     // 3. rows into image order on the first device
     return enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
@@ -456,11 +524,12 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
 int pt_multi_sync(PtMulti* m) {
     if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
     int rc = multi_drain(m);            // every posted frame is enqueued on the streams ...
-    for (PtContext* c : m->ctx) {       // ... and now complete on them
+    for (PtContext* c : m->ctx) {       // ... and now complete on them: the renders,
         const int r2 = pt_sync(c);
         if (!rc) rc = r2;
     }
-    return rc;
+    const int r3 = sync_exchange(m);    // then the gather and the row permutation behind them
+    return rc ? rc : r3;
 }
 
 // Counters of the frames since the last collection summed over the devices (times: the slowest device).

@@ -69,7 +69,18 @@ class FilmGather:
     overlaps the rendering of frame k + 1 (bench.py); calling the object does both at once.
 
     Both film planes travel together: the f32 linear plane [rows, W, 3] and the RGBA8 plane [rows, W, 4] are
-    packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel)."""
+    packed into a [rows, W, 16] byte tile (12 + 4 bytes per pixel).
+
+    On a GPU the exchange has a stream of its own and a RING of send tiles (round 4).  The collective's kernel can be late:
+    a rank that renders frame after frame keeps three regenerating launches in flight (pt_api.cpp: lanes), and RCCL's kernel
+    -- one workgroup of 4 x 136 VGPRs -- is not placed beside them until the launches run out of work
+    (profiles/r04/gather_kernel_beside_lanes.txt).  A wait for the gather in the render stream therefore stalled the whole
+    pipeline once per frame.  Now the render stream only records `tile written`; gather, wait and row permutation are
+    enqueued on the exchange stream; and the render stream waits for a gather only when it wants that gather's tile back,
+    RING_MAX frames later.  finish() makes the caller's stream wait for the last frame."""
+
+    RING_MAX = 8                # send tiles on a GPU (host tensors: 2) ...
+    RING_BYTES = 1 << 30        # ... fewer when this would not hold that many
 
     def __init__(self, height, width, band_rows, rank, world_size, device, group=None, dst=0, always_collective=False):
         rows = [tile_row_indices(height, band_rows, g, world_size) for g in range(world_size)]
@@ -79,8 +90,16 @@ class FilmGather:
         self.max_rows = max(len(r) for r in rows)
         # two send tiles: with pre-packed renders (start_prepacked) the render of frame k + 1 writes one while the gather of
         # frame k, running on the backend's stream, still reads the other
-        self._sends = [torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+        self._streamed = torch.device(device).type == "cuda"
+        n_send = 2
+        if self._streamed:
+            n_send = int(min(self.RING_MAX, max(2, self.RING_BYTES // max(1, self.max_rows * width * 16))))
+        self._sends = [torch.zeros((self.max_rows, width, 16), dtype=torch.uint8, device=device) for _ in range(n_send)]
         self._cur, self._pending_buf = 0, None
+        if self._streamed:
+            self._xs = torch.cuda.Stream(device)             # gather, wait for it, row permutation
+            self._sent = [None] * n_send                     # per send tile: the event after the gather that read it
+            self._last_ev, self._frames, self._outs = None, 0, None
         self.recv = self.bufs = self.perm = None
         self._work, self._pending, self._last = None, False, (None, None)
         # world_size 1 needs no exchange; always_collective issues the gather anyway (bench.py --force-dist: the whole
@@ -94,6 +113,9 @@ class FilmGather:
                 for k, y in enumerate(rows[g]):
                     perm[y] = g * self.max_rows + k
             self.perm = torch.tensor(perm, dtype=torch.int64).to(device)
+            if self._streamed:   # two frames of output, written in turn by the exchange stream
+                self._outs = [(torch.empty((height, width, 3), dtype=torch.float32, device=device),
+                               torch.empty((height, width, 4), dtype=torch.uint8, device=device)) for _ in range(2)]
 
     @property
     def send(self):
@@ -104,6 +126,9 @@ class FilmGather:
         """Pack this rank's tile and launch the gather without waiting for it (async_op): the collective runs
         on the backend's own stream / thread while the caller renders the next frame.  A previous gather still in
         flight is completed first (its frame is then available from finish())."""
+        if self._streamed:
+            self._pack(lin, rgba)
+            return self._start_streamed()
         if self._work is not None or self._pending:
             self._last = self.finish()
         self._pack(lin, rgba)
@@ -118,7 +143,9 @@ class FilmGather:
         have been enqueued on torch's current stream of the device, where the gather is ordered.  Afterwards self.send is
         the OTHER tile: the caller may enqueue the next render into it at once -- this gather keeps reading the one it was
         given, and by the time that one is written again (two frames on) the start of the frame in between has waited
-        for this gather."""
+        for this gather.  (GPU tiles: a ring of RING_MAX tiles and an exchange stream, see the class comment.)"""
+        if self._streamed:
+            return self._start_streamed()
         if self._work is not None or self._pending:
             self._last = self.finish()
         self._pending_buf = self.send
@@ -127,9 +154,41 @@ class FilmGather:
         self._cur ^= 1
         self._pending = True
 
+    def _start_streamed(self):
+        """GPU form of start(): the tile in self.send was written by work enqueued on torch's current stream.  Everything
+        here is an enqueue; nothing waits on the host."""
+        buf = self.send
+        cur = torch.cuda.current_stream(buf.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self._xs):
+            self._xs.wait_event(ready)
+            if self._collective:
+                work = dist.gather(buf, gather_list=self.bufs, dst=self.dst, group=self.group, async_op=True)
+                work.wait()                                  # the exchange stream waits for the backend's stream
+            if self.rank == self.dst:
+                src = self.recv.view(self.world * self.max_rows, self.width, 16) if self._collective else buf
+                self._unpack(src, self._outs[self._frames % 2])
+            sent = torch.cuda.Event()
+            sent.record(self._xs)
+        self._sent[self._cur] = self._last_ev = sent
+        self._frames += 1
+        self._cur = (self._cur + 1) % len(self._sends)
+        if self._sent[self._cur] is not None:                # the tile the next frame goes into: its last gather has read it
+            cur.wait_event(self._sent[self._cur])
+        self._pending = True
+
     def finish(self):
         """Wait for the gather launched by start() and return (linear [H, W, 3] f32, rgba [H, W, 4] u8) on `dst`,
-        (None, None) elsewhere.  Without a pending gather: the frame of the last one completed by start()."""
+        (None, None) elsewhere.  Without a pending gather: the frame of the last one completed by start().
+        GPU tiles: torch's current stream waits (the host does not); the tensors returned are the exchange's own two
+        output frames, written in turn -- copy what must outlive the next two start() calls."""
+        if self._streamed:
+            if not self._pending:
+                return None, None
+            torch.cuda.current_stream(self._sends[0].device).wait_event(self._last_ev)
+            self._pending = False
+            return self._outs[(self._frames - 1) % 2] if self.rank == self.dst else (None, None)
         if not self._pending:
             last, self._last = self._last, (None, None)
             return last
@@ -155,13 +214,16 @@ class FilmGather:
             self.send[:n, :, :12] = lin.contiguous().reshape(-1).view(torch.uint8).reshape(n, w, 12)
             self.send[:n, :, 12:] = rgba
 
-    def _unpack(self, src):
+    def _unpack(self, src, out=None):
         """Gathered padded tiles [world * max_rows, W, 16] -> (linear [H, W, 3] f32, rgba [H, W, 4] u8) in image order."""
         w = self.width
         if src.is_cuda:
             # the library's unpack kernel (pt_film_unpack): gathered padded tiles -> both film planes in image order
-            lin_full = torch.empty((self.height, w, 3), dtype=torch.float32, device=src.device)
-            rgba_full = torch.empty((self.height, w, 4), dtype=torch.uint8, device=src.device)
+            if out is not None:
+                lin_full, rgba_full = out
+            else:
+                lin_full = torch.empty((self.height, w, 3), dtype=torch.float32, device=src.device)
+                rgba_full = torch.empty((self.height, w, 4), dtype=torch.uint8, device=src.device)
             with torch.cuda.device(src.device):
                 _check(_lib().pt_film_unpack(_stream_ptr(src.device), src.data_ptr(), w, self.height, self.band_rows, self.world,
                                              self.max_rows, lin_full.data_ptr(), rgba_full.data_ptr()))
@@ -186,7 +248,10 @@ def gather_film(lin, rgba, height, band_rows, rank, world_size, group=None, dst=
     plan = _plans.get(key)
     if plan is None:
         plan = _plans[key] = FilmGather(height, lin.shape[1], band_rows, rank, world_size, lin.device, group, dst)
-    return plan(lin, rgba)
+    out = plan(lin, rgba)
+    if plan._streamed and out[0] is not None:        # the plan's own output frames are written again two frames on
+        out = (out[0].clone(), out[1].clone())
+    return out
 
 
 def render_distributed(ctx, cam, params, rank, world_size, band_rows=None, group=None, want_rgba=True):

@@ -684,3 +684,52 @@ def test_film_pack_and_unpack_kernels_of_the_per_process_form(pt, H, W, band, n)
         assert torch.equal(out_rgba.cpu(), rgba), str(device)
     with pytest.raises(pt._lib.PtError, match="max_rows"):
         pt._lib.check(pt._lib.lib().pt_film_unpack(None, recv.data_ptr(), W, H, band, n, 0, out_lin.data_ptr(), None))
+
+
+@pytest.mark.gpu
+def test_streamed_film_exchange_over_rccl_keeps_every_frame(pt):
+    """The per-process form's exchange on a GPU (pathtrace_amd/dist.py, FilmGather): a ring of send tiles, and gather + wait +
+    row permutation on a stream of their own, so that a late collective holds up nothing but the frame that wants its tile
+    back.  One rank over the real backend (RCCL, world size 1, the gather issued regardless): 21 different frames -- more than
+    two rounds of the ring -- are rendered by the film resolve straight into the ring's tiles and started back to back without a
+    host wait; the frames collected on the way and the last one equal plain renders bit for bit, and the tiles are taken in turn."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pathtrace_amd.dist import FilmGather
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    ctx = None
+    try:
+        dev = torch.device("cuda", 0)
+        H, W, band = 96, 64, 8
+        cam = pt.camera_new(width=W, height=H)
+        ctx = pt.Context(0)
+        ctx.upload(pt.builtin_scene(2))
+        frames = 21
+        prms = [pt.default_params(spp=8, spp_offset=8 * k, band_rows=band, band_index=0, band_count=1) for k in range(frames)]
+        ref = [ctx.render(cam, p) for p in prms]
+        assert not torch.equal(ref[0][0], ref[1][0])
+        fg = FilmGather(H, W, band, 0, 1, dev, always_collective=True)
+        assert len(fg._sends) == FilmGather.RING_MAX and fg._streamed
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ptrs, checked = [], 0
+        for k in range(frames):
+            ptrs.append(fg.send.data_ptr())
+            ctx.render_packed_into(cam, prms[k], fg.send.data_ptr())
+            fg.start_prepacked()
+            if k % 5 == 4 or k + 1 == frames:
+                lin, rgba = fg.finish()
+                torch.cuda.current_stream(dev).synchronize()
+                assert torch.equal(lin.view(torch.int32), ref[k][0].view(torch.int32)), k
+                assert torch.equal(rgba, ref[k][1]), k
+                checked += 1
+        assert checked == 5 and fg.finish() == (None, None)
+        ring = FilmGather.RING_MAX
+        assert len(set(ptrs[:ring])) == ring and ptrs[ring:2 * ring] == ptrs[:ring] and ptrs[2 * ring] == ptrs[0]
+        ctx.sync()
+    finally:
+        if ctx is not None:
+            ctx.set_stream(None)
+            ctx.close()
+        dist.destroy_process_group()
