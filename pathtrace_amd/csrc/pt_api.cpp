@@ -206,6 +206,9 @@ struct PtContext {
     uint32_t profiled_batches = 0;             // event slots (launch begin / end pairs) in use since the statistics were last collected
     std::vector<uint32_t> primary_events;      // slots of the level-0 launches
     PtTuning tuning{};                         // pt_context_set_tuning; 0 = library default
+    uint32_t* h_posted = nullptr;              // host memory the device reads: number of the last lanes launch enqueued (BounceArgs.posted)
+    uint32_t* d_posted = nullptr;              // ... its device address
+    uint32_t lane_seq = 0;
     bool bvh_failed = false;                   // the BVH builder refused this scene (depth): PT_ACCEL_AUTO stays with the scan
     // pixel-list entries (pt_render_pixels, pt_ray_color)
     DevBuf<uint2> pixel_list;
@@ -406,6 +409,12 @@ int pt_context_create(int device, PtContext** out) {
         delete c;
         return fail(PT_ERR_HIP, "hipEventCreate failed");
     }
+    if (hipHostMalloc((void**)&c->h_posted, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->d_posted, c->h_posted, 0) != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "context allocation failed (mapped host word)");
+    }
+    *c->h_posted = 0u;
     if (hipHostMalloc((void**)&c->h_dstats, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_ovf, 4 * sizeof(uint32_t)) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
@@ -446,6 +455,7 @@ int pt_context_destroy(PtContext* c) {
     c->xchg.release();
     c->ovf_count.release();
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
+    if (c->h_posted) (void)hipHostFree(c->h_posted);
     c->lsamp.release(); c->film.release(); c->host_lin.release(); c->host_rgba.release();
     c->pixel_list.release(); c->fn_in.release(); c->fn_out.release(); c->fn_words.release();
     for (auto& b : c->inject) b.release();
@@ -745,23 +755,16 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         lanes = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
         (void)hipGetLastError();
     }
-    // With lanes a launch takes LESS than half of what the device holds (kLaneGrid24 / 24 of it): two consecutive launches are then
-    // resident side by side, a phase apart, and the third fills the slots the first frees while it runs dry -- the device never waits
-    // for one launch's last waves.  Measured (tools/r04/share_grid.py, C2, ms per render, 3 lanes): the whole image 6.01 with
-    // full-size launches, 5.69 at 704 of 1536 workgroups (5.82 at exactly half: no room for the third); one rank's share at 8
-    // ranks 0.95 -> 0.78.  A launch that runs alone (in order) takes the whole device as before.
-    // ... which needs three launches in flight: a render of three or more sample batches, or a caller that enqueues renders back
-    // to back (the previous launch has not completed when this one is enqueued).  A launch on its own -- a host that synchronises
-    // after every render -- still takes the whole device.
-    if (lanes && !prm->workgroups && !c->tuning.regen_workgroups) {
-        bool neighbours = n_batches >= 3;
-        if (!neighbours) {
-            const int last = (int)((c->lane_next + (uint32_t)kLanes - 1u) % (uint32_t)kLanes);       // lane of the most recent launch
-            neighbours = c->lane_used[last] && hipEventQuery(c->lane_done[last]) == hipErrorNotReady;
-            (void)hipGetLastError();
-        }
-        if (neighbours) regen_grid = std::max(1u, regen_capacity * kLaneGrid24 / 24u);
-    }
+    // With lanes the first kLaneGrid24 / 24 of a launch's workgroups -- LESS than half of what the device holds -- are its core, the
+    // others spare (BounceArgs.posted): in a sequence of launches two cores are resident side by side, a phase apart, and the third
+    // fills the slots the first frees while it runs dry -- the device never waits for one launch's last waves -- while the spare
+    // workgroups end as soon as they get a slot and see that two launches are enqueued behind theirs.  Those of the last two
+    // launches of a sequence, and of a launch on its own (a host that synchronises after every render), see no such successors
+    // and take the rest of the device.  Measured (tools/r04/share_grid.py, C2, ms per render, 3 lanes): the whole image 6.01 with
+    // full-size launches, 5.69 with cores of 704 of 1536 workgroups (5.82 at exactly half: no room for the third); one rank's
+    // share at 8 ranks 0.95 -> 0.78.  A launch that runs in order takes the whole device as before.
+    uint32_t regen_core = 0;                      // 0: no spare workgroups
+    if (lanes && !prm->workgroups && !c->tuning.regen_workgroups) regen_core = std::max(1u, regen_capacity * kLaneGrid24 / 24u);
     const bool two_sets = overlap || lanes;      // both parities of sample buffer / launch counters / hand-over queue in use
 
     int rc;
@@ -926,6 +929,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             a.debug_tag = (uint32_t)par;
             a.chunk_counter = nullptr;
             a.xchg = nullptr;
+            a.posted = nullptr; a.seq = 0; a.core_blocks = 0;
             if (level == 0 && regen) {
                 a.chunk_counter = d_count + ptk::kRegenCounterStride;
                 if (split) a.xchg = c->xchg.p + (lanes ? (size_t)lane * xchg_lane : 0);
@@ -936,6 +940,12 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 // (none with lanes: a workgroup of this launch that only finds room when the previous launch's last waves end
                 // would carry its dealt share as a serial tail)
                 a.regen_static = lanes ? 0u : (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
+                if (regen_core && regen_core < g) {              // spare workgroups beyond the core (see above)
+                    a.posted = c->d_posted;
+                    a.seq = ++c->lane_seq;
+                    a.core_blocks = regen_core;
+                    __atomic_store_n(c->h_posted, c->lane_seq, __ATOMIC_RELEASE);      // before the launch is handed to the device
+                }
             }
             if (hand_off) c->counters_clean[par] = false;       // until this batch's resolve has cleared them again
             if (profile) {

@@ -92,6 +92,11 @@ struct BounceArgs {
     // launch kXqF4PerWave float4 of exchange stacks + parking area
     float4* xchg;
     uint32_t regen_static;    // chunks dealt round-robin to the waves (a multiple of the launch's wave count); the rest by the counters
+    // non-null (regenerating launches that overlap their neighbours: pt_api.cpp, lanes): the workgroups from core_blocks on are
+    // SPARE -- each reads *posted (host memory: launches the host has enqueued so far) when it starts and ends at once if two
+    // or more launches follow this one (seq = this launch's number); otherwise it works like any other
+    const uint32_t* posted;
+    uint32_t seq, core_blocks;
     uint32_t src_mode;        // 0: pass 0 generates camera rays, 1: pass 0 reads ovf_in
     uint32_t export_below;    // >= 1; 1 = never export (a wave runs until its segment is empty)
     uint32_t seg_cap;         // slots per segment (multiple of 64)

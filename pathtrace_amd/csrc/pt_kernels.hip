@@ -856,6 +856,16 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
     if (threadIdx.x < kRegenBlock / 64) { s_mail_cnt[threadIdx.x] = 0u; s_mail_head[threadIdx.x] = 0u; }
     if (threadIdx.x == 0u) s_active = kRegenBlock / 64;
 #endif
+    // Spare workgroups (BounceArgs.posted): in a sequence of overlapping launches only the first core_blocks of a launch work -- two
+    // launches then sit side by side and the third fills the slots the first frees while it runs dry -- but the LAST launches of
+    // a sequence, and a launch on its own, would leave half of the device empty.  So every launch brings a full device's worth of
+    // workgroups, and a spare one asks, when it gets its slot, whether successors are waiting for it: yes -> it ends at once.
+    if (a.posted != nullptr && blockIdx.x >= a.core_blocks) {
+        __shared__ uint32_t s_posted;
+        if (threadIdx.x == 0u) s_posted = __hip_atomic_load(a.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (s_posted - a.seq >= 2u) return;
+    }
     const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);          // (its barrier also publishes the words above)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;
@@ -1157,6 +1167,12 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     __shared__ float4 s_pool_d[kBlock / 64][kPool];
     __shared__ uint32_t s_pool_s[kBlock / 64][kPool];
     __shared__ float4 s_stage[kBlock / 64][4][64];       // a batch's survivors while the scan of their next vertex decides their stack (plane-major: conflict-free)
+    if (a.posted != nullptr && blockIdx.x >= a.core_blocks) {       // spare workgroup (see k_paths_regen)
+        __shared__ uint32_t s_posted;
+        if (threadIdx.x == 0u) s_posted = __hip_atomic_load(a.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (s_posted - a.seq >= 2u) return;
+    }
     const SceneRef sc = stage_scene<kModeLds>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wib = threadIdx.x >> 6;
@@ -1854,7 +1870,9 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
     }
     if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen*)
         const uint32_t block = a.xchg ? kBlock : kRegenBlock;    // grid = number of 4-wave units
-        hipLaunchKernelGGL(regen_kernel(a), dim3(std::max(1u, grid * kBlock / block)), dim3(block), lds, st, a);
+        BounceArgs b = a;
+        b.core_blocks = a.core_blocks * kBlock / block;          // (given in four-wave units like the grid)
+        hipLaunchKernelGGL(regen_kernel(a), dim3(std::max(1u, grid * kBlock / block)), dim3(block), lds, st, b);
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }
