@@ -85,7 +85,11 @@ constexpr bool kLaneOverlap = PT_LANE_OVERLAP != 0;
 #ifndef PT_LANE_GRID24
 #define PT_LANE_GRID24 11
 #endif
-constexpr uint32_t kLaneGrid24 = PT_LANE_GRID24;      // grid of a launch that shares the device with its neighbours, in 24ths of what the device holds
+constexpr uint32_t kLaneGrid24 = PT_LANE_GRID24;      // core of a launch that overlaps its neighbours, in 24ths of what the device holds (k_paths_regen)
+#ifndef PT_LANE_GRID24_SPLIT
+#define PT_LANE_GRID24_SPLIT 12
+#endif
+constexpr uint32_t kLaneGrid24Split = PT_LANE_GRID24_SPLIT;   // ... k_paths_regen_split (5 workgroups per CU): C1 7.26 ms per step at 11, 7.13 at 12, 7.18 at 13
 constexpr int kLanes = PT_LANES;        // streams the regenerating launches of consecutive batches take in turn (2 or 3)
 constexpr uint32_t kStatsWords = 32;            // 16 x u64 at the front of the counter buffer: 8 render statistics, 8 words for measurement builds (PT_DRAIN_TIMING)
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
@@ -762,9 +766,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // launches of a sequence, and of a launch on its own (a host that synchronises after every render), see no such successors
     // and take the rest of the device.  Measured (tools/r04/share_grid.py, C2, ms per render, 3 lanes): the whole image 6.01 with
     // full-size launches, 5.69 with cores of 704 of 1536 workgroups (5.82 at exactly half: no room for the third); one rank's
-    // share at 8 ranks 0.95 -> 0.78.  A launch that runs in order takes the whole device as before.
+    // share at 8 ranks 0.95 -> 0.78; cores of 9 .. 11 / 24 are within noise of one another on C2 (5.65 - 5.68 ms per step), 12 and
+    // 13 cost 3 - 4 % (profiles/r04/ab_lane_core_size.txt).  A launch that runs in order takes the whole device as before.
     uint32_t regen_core = 0;                      // 0: no spare workgroups
-    if (lanes && !prm->workgroups && !c->tuning.regen_workgroups) regen_core = std::max(1u, regen_capacity * kLaneGrid24 / 24u);
+    if (lanes && !prm->workgroups && !c->tuning.regen_workgroups) regen_core = std::max(1u, regen_capacity * (split ? kLaneGrid24Split : kLaneGrid24) / 24u);
     const bool two_sets = overlap || lanes;      // both parities of sample buffer / launch counters / hand-over queue in use
 
     int rc;

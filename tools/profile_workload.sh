@@ -12,6 +12,9 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
 python3 $ARGS > $OUT/bench_plain.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json
+# counter passes: every launch in order and full size (--in-order), like the launches bench.py takes its launch time from -- a counter
+# pass serialises the kernels anyway, and an overlapping launch run alone would work with its core workgroups only (pt_api.cpp, lanes)
+ARGS="$ARGS --in-order"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_pmc_fetch.json
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_pmc_write.json
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_pmc_sq.json
