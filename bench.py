@@ -195,6 +195,9 @@ def main(argv=None):
     ap.add_argument("--in-order", action="store_true",
                     help="round 3's method: PtTuning.in_order = 1 (consecutive launches never overlap) and HIP events around every launch of "
                          "the timed steps; default: the timed steps overlap and the launch times come from 3 in-order steps after them")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "copy"],
+                    help="single-process multi-device form: how the tiles reach device 0 -- one ncclGather per frame (default) or one DMA "
+                         "copy per device (pt_multi_set_exchange: no kernel takes part in the exchange)")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (64*N spp) instead of the strong-scaling default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal on a box with fewer GPUs than ranks (ranks share devices, the gather "
@@ -262,6 +265,8 @@ def main(argv=None):
         ctx = pt.Multi(list(range(world)), shared_device=0 if args.shared_device else None)
         ctx.upload(objs)
         ctx.set_tuning(**tuning)
+        if args.exchange != "rccl":
+            ctx.set_exchange(args.exchange)
         rows = HEIGHT                           # the frame is assembled on device 0 by the library
     else:
         prm = pt.default_params(band_rows=band_rows, band_index=rank, band_count=world, **common)
@@ -532,6 +537,7 @@ def main(argv=None):
             # proof that N ranks took part: the communicator's own count and the library version, plus what a frame costs the host
             out["config"]["rccl"] = {"ncclCommCount": int(multi_info.comm_count), "version": int(multi_info.rccl_version),
                                      "host_threads": int(multi_info.threaded) * world,
+                                     "exchange": "copies by the DMA engines (pt_multi_set_exchange)" if int(multi_info.exchange) else "ncclGather",
                                      "enqueue_us_per_frame_slowest_device": round(multi_info.enqueue_us_max, 1),
                                      "enqueue_us_per_frame_all_devices": round(multi_info.enqueue_us_sum, 1)}
         elif dist_path:

@@ -278,6 +278,13 @@ int pt_multi_create(const int* devices, uint32_t n_devices, PtMulti** out);   /*
 int pt_multi_destroy(PtMulti* m);
 uint32_t pt_multi_device_count(const PtMulti* m);
 int pt_multi_set_threads(PtMulti* m, int enabled);
+/* How the tiles reach the first device.  PT_EXCHANGE_RCCL (default): one ncclGather per frame.  PT_EXCHANGE_COPY: every device
+ * copies its tile into the root's receive buffer with the DMA engines (hipMemcpyPeerAsync over xGMI) and the root waits for the n
+ * copies -- no kernel takes part, so the exchange never waits for wave slots beside the render (RCCL's gather kernel does, see
+ * pt_multi.cpp).  Same frame bit for bit.  Exercised on one device only (a same-device copy), like everything with n > 1.   */
+#define PT_EXCHANGE_RCCL 0u
+#define PT_EXCHANGE_COPY 1u
+int pt_multi_set_exchange(PtMulti* m, uint32_t mode);
 int pt_multi_scene_upload(PtMulti* m, const PtObject* objs, uint32_t n_objs);  /* replicated on every device */
 int pt_multi_set_tuning(PtMulti* m, const PtTuning* tuning);                   /* pt_context_set_tuning on every device's context */
 /* Post one frame: d_linear_rgb (H*W*3 floats) / d_rgba8 (H*W*4 bytes or NULL) are buffers on the FIRST device.
@@ -297,6 +304,8 @@ typedef struct {
     uint64_t frames;          /* frames posted since creation                                                       */
     double   enqueue_us_sum;  /* host time spent enqueueing one frame, summed over the devices (mean per frame) ...  */
     double   enqueue_us_max;  /* ... and the slowest device's share of it: what a frame costs the host with threads  */
+    uint32_t exchange;        /* PT_EXCHANGE_*                                                                      */
+    uint32_t reserved_;
 } PtMultiInfo;
 int pt_multi_info(PtMulti* m, PtMultiInfo* out);
 /* One shot with host buffers (a cached PtMulti for the device list; pt_shutdown frees it). */

@@ -91,9 +91,12 @@ class PtMultiInfo(C.Structure):
         ("frames", C.c_uint64),
         ("enqueue_us_sum", C.c_double),
         ("enqueue_us_max", C.c_double),
+        ("exchange", C.c_uint32),
+        ("reserved_", C.c_uint32),
     ]
 
 
+PT_EXCHANGE_RCCL, PT_EXCHANGE_COPY = 0, 1
 PT_SHAPE_SPHERE, PT_SHAPE_TRIANGLE = 0, 1
 PT_MAT_LAMBERT, PT_MAT_EMISSIVE, PT_MAT_MIRROR, PT_MAT_OREN_NAYAR = 0, 1, 2, 3
 PT_INTEGRATOR_MIS, PT_INTEGRATOR_BRDF_ONLY = 0, 1
@@ -143,6 +146,7 @@ SYMBOLS = {
     "pt_multi_destroy": (C.c_int, [C.c_void_p]),
     "pt_multi_device_count": (C.c_uint32, [C.c_void_p]),
     "pt_multi_set_threads": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pt_multi_info": (C.c_int, [C.c_void_p, _P(PtMultiInfo)]),
     "pt_debug_multi_create_shared": (C.c_int, [C.c_int, C.c_uint32, _P(C.c_void_p)]),
     "pt_debug_feeder_selftest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _P(C.c_uint64), _P(C.c_uint32)]),

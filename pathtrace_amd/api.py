@@ -297,6 +297,10 @@ class Multi:
     def set_threads(self, enabled):
         check(lib().pt_multi_set_threads(self._h, 1 if enabled else 0))
 
+    def set_exchange(self, mode):
+        """pt_multi_set_exchange: "rccl" (one ncclGather per frame, default) or "copy" (one DMA copy per device, no kernel)."""
+        check(lib().pt_multi_set_exchange(self._h, {"rccl": _lib.PT_EXCHANGE_RCCL, "copy": _lib.PT_EXCHANGE_COPY}[mode]))
+
     def info(self):
         i = _lib.PtMultiInfo()
         check(lib().pt_multi_info(self._h, C.byref(i)))

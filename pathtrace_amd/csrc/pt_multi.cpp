@@ -164,6 +164,10 @@ struct PtMulti {
     // into the receive buffer on its own stream where the real object runs ncclGather.  Host latches keep the emulation's
     // events in frame order (the collective does that by itself).
     bool shared = false;
+    // Exchange by copies instead of ncclGather (pt_multi_set_exchange; always for the debug object): device g's exchange stream
+    // copies its tile into the root's receive buffer (hipMemcpyPeerAsync: the DMA engines over xGMI, no kernel on any CU), the
+    // root's waits for the n `copied` events.  The same events and latches as the debug object.
+    bool copy = false;
     std::vector<hipEvent_t> ev_copied;
     hipEvent_t ev_unpacked = nullptr;
     std::mutex lat_mu;
@@ -220,8 +224,8 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
     // (a failed render still takes part in the gather below: the other devices' gather calls would wait for this one for ever)
     HIP_TRY(hipEventRecord(m->ev_ready[slot], st));
     HIP_TRY(hipStreamWaitEvent(xs, m->ev_ready[slot], 0));
-    if (m->shared) {
-        // emulated gather: the tile goes to its place in the receive buffer once the row permutation of the previous
+    if (m->copy) {
+        // gather by copies: the tile goes to its place in the receive buffer once the row permutation of the previous
         // frame has read it
         if (frame > 1) {
             std::unique_lock<std::mutex> lk(m->lat_mu);
@@ -229,7 +233,9 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
             lk.unlock();
             HIP_TRY(hipStreamWaitEvent(xs, m->ev_unpacked, 0));
         }
-        HIP_TRY(hipMemcpyAsync((char*)m->recv.p + (size_t)g * fs.tile_px * 16, m->packed[slot].p, fs.tile_px * 16, hipMemcpyDeviceToDevice, xs));
+        char* const dst = (char*)m->recv.p + (size_t)g * fs.tile_px * 16;
+        if (m->devices[g] == m->devices[0]) HIP_TRY(hipMemcpyAsync(dst, m->packed[slot].p, fs.tile_px * 16, hipMemcpyDeviceToDevice, xs));
+        else HIP_TRY(hipMemcpyPeerAsync(dst, m->devices[0], m->packed[slot].p, m->devices[g], fs.tile_px * 16, xs));
         HIP_TRY(hipEventRecord(m->ev_copied[g], xs));
         HIP_TRY(hipEventRecord(m->ev_sent[slot], xs));
         { std::lock_guard<std::mutex> lk(m->lat_mu); m->copied_frame[g] = frame; }
@@ -247,7 +253,7 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
 int enqueue_root_tail(PtMulti* m, const FrameShape& fs, uint64_t frame, float* d_linear, uint8_t* d_rgba) {
     HIP_TRY(hipSetDevice(m->devices[0]));
     hipStream_t st = m->xs[0];
-    if (m->shared) {
+    if (m->copy) {
         {
             std::unique_lock<std::mutex> lk(m->lat_mu);
             m->lat_cv.wait(lk, [&] { for (uint64_t f : m->copied_frame) if (f < frame) return false; return true; });
@@ -256,11 +262,25 @@ int enqueue_root_tail(PtMulti* m, const FrameShape& fs, uint64_t frame, float* d
     }
     ptk::launch_film_unpack(m->recv.p, fs.W, fs.H, fs.band_rows, fs.n, fs.max_rows, d_linear, d_rgba, st);
     HIP_TRY(hipGetLastError());
-    if (m->shared) {
+    if (m->copy) {
         HIP_TRY(hipEventRecord(m->ev_unpacked, st));
         { std::lock_guard<std::mutex> lk(m->lat_mu); m->unpacked_frame = frame; }
         m->lat_cv.notify_all();
     }
+    return PT_OK;
+}
+
+// Events and latches of the exchange by copies: `copied` per device (on that device), `unpacked` on the root
+int copy_events(PtMulti* m) {
+    const size_t n = m->devices.size();
+    m->copied_frame.assign(n, 0);
+    m->ev_copied.assign(n, nullptr);
+    for (size_t g = 0; g < n; ++g) {
+        HIP_TRY(hipSetDevice(m->devices[g]));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_copied[g], hipEventDisableTiming));
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_unpacked, hipEventDisableTiming));
     return PT_OK;
 }
 
@@ -274,7 +294,7 @@ int multi_alloc(uint32_t n, const int* devices, bool shared, PtMulti** out) {
     m->ev_sent.assign((size_t)n * kSendSlots, nullptr);
     m->slot_used.assign((size_t)n * kSendSlots, 0);
     m->enqueue_us.assign(n, 0.0);
-    m->shared = shared;
+    m->shared = m->copy = shared;
     int rc;
     auto streams = [&](uint32_t i) -> int {
         HIP_TRY(hipSetDevice(devices[i]));
@@ -384,16 +404,34 @@ int pt_debug_multi_create_shared(int device, uint32_t n, PtMulti** out) {
     PtMulti* m = nullptr;
     int rc;
     if ((rc = multi_alloc(n, devs.data(), true, &m))) return rc;
-    m->copied_frame.assign(n, 0);
-    m->ev_copied.assign(n, nullptr);
-    auto events = [&]() -> int {
-        HIP_TRY(hipSetDevice(device));
-        for (uint32_t g = 0; g < n; ++g) HIP_TRY(hipEventCreateWithFlags(&m->ev_copied[g], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_unpacked, hipEventDisableTiming));
-        return PT_OK;
-    };
-    if ((rc = events())) { pt_multi_destroy(m); return rc; }
+    if ((rc = copy_events(m))) { pt_multi_destroy(m); return rc; }
     *out = m;
+    return PT_OK;
+}
+
+// PT_EXCHANGE_RCCL (default): ONE ncclGather per frame.  PT_EXCHANGE_COPY: every device copies its tile to the root with the DMA
+// engines (hipMemcpyPeerAsync) -- no kernel takes part, so nothing has to find room beside the regenerating launches (RCCL's
+// kernel does not: pt_multi.cpp head).  Same frame either way.  Frames in flight are completed first.
+int pt_multi_set_exchange(PtMulti* m, uint32_t mode) {
+    if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
+    if (mode != PT_EXCHANGE_RCCL && mode != PT_EXCHANGE_COPY) return pt_internal_fail(PT_ERR_INVALID_ARG, "pt_multi_set_exchange: unknown mode %u", mode);
+    if (m->shared) return mode == PT_EXCHANGE_COPY ? PT_OK : pt_internal_fail(PT_ERR_UNSUPPORTED, "a shared-device debug object has no RCCL communicators");
+    int rc = multi_quiesce(m);
+    if (rc) return rc;
+    if (mode == PT_EXCHANGE_COPY && m->ev_copied.empty()) {
+        if ((rc = copy_events(m))) return rc;
+        for (size_t g = 1; g < m->devices.size(); ++g) {       // direct copies over xGMI where the devices allow it (else staged by the runtime)
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->devices[g], m->devices[0]) == hipSuccess && can) {
+                (void)hipSetDevice(m->devices[g]);
+                (void)hipDeviceEnablePeerAccess(m->devices[0], 0);
+            }
+            (void)hipGetLastError();                            // "already enabled" is fine
+        }
+    }
+    // the latches count frames: both forms start from the frames posted so far
+    { std::lock_guard<std::mutex> lk(m->lat_mu); m->unpacked_frame = m->frames; for (auto& f : m->copied_frame) f = m->frames; }
+    m->copy = mode == PT_EXCHANGE_COPY;
     return PT_OK;
 }
 
@@ -417,6 +455,7 @@ int pt_multi_info(PtMulti* m, PtMultiInfo* out) {
     PtMultiInfo info{};
     info.n_devices = (uint32_t)m->devices.size();
     info.threaded = m->feeder ? 1u : 0u;
+    info.exchange = m->copy ? PT_EXCHANGE_COPY : PT_EXCHANGE_RCCL;
     info.frames = m->frames;
     if (!m->comm.empty() && m->comm[0]) {
         int cnt = 0, ver = 0;
@@ -504,7 +543,7 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
         timed(g, t0);
     }
     // 2. ONE gather of the padded tiles to the first device (ncclGather, rccl.h:745), every device on its exchange stream
-    if (!m->shared) {
+    if (!m->copy) {
         const size_t k = (size_t)((frame - 1) % m->ring);
         NCCL_TRY(g_rccl.GroupStart());
         for (uint32_t g = 0; g < n; ++g) {

@@ -105,7 +105,11 @@ pub struct PtMultiInfo {
     pub frames: u64,
     pub enqueue_us_sum: f64,
     pub enqueue_us_max: f64,
+    pub exchange: u32,
+    pub reserved_: u32,
 }
+pub const PT_EXCHANGE_RCCL: u32 = 0;
+pub const PT_EXCHANGE_COPY: u32 = 1;
 
 #[repr(C)]
 pub struct PtContext {
@@ -148,6 +152,7 @@ extern "C" {
     pub fn pt_multi_destroy(m: *mut PtMulti) -> c_int;
     pub fn pt_multi_device_count(m: *const PtMulti) -> u32;
     pub fn pt_multi_set_threads(m: *mut PtMulti, enabled: c_int) -> c_int;
+    pub fn pt_multi_set_exchange(m: *mut PtMulti, mode: u32) -> c_int;
     pub fn pt_multi_info(m: *mut PtMulti, out: *mut PtMultiInfo) -> c_int;
     pub fn pt_debug_multi_create_shared(device: c_int, n: u32, out: *mut *mut PtMulti) -> c_int;
     pub fn pt_debug_feeder_selftest(n_workers: u32, n_frames: u32, spin: u32, fail_at: i32, order_out: *mut u64, n_out: *mut u32) -> c_int;

@@ -194,6 +194,12 @@ impl Multi {
     pub fn set_threads(&mut self, enabled: bool) -> Result<(), Error> {
         check(unsafe { sys::pt_multi_set_threads(self.m, enabled as i32) })
     }
+
+    /// How the tiles reach the first device: one `ncclGather` per frame (`false`, the default) or one copy per device by
+    /// the DMA engines (`true`: no kernel takes part in the exchange).  Same frame either way.
+    pub fn set_exchange_by_copies(&mut self, copies: bool) -> Result<(), Error> {
+        check(unsafe { sys::pt_multi_set_exchange(self.m, if copies { sys::PT_EXCHANGE_COPY } else { sys::PT_EXCHANGE_RCCL }) })
+    }
     /// Devices, `ncclCommCount`, RCCL version, frames posted and what a frame costs the host.
     pub fn info(&mut self) -> Result<sys::PtMultiInfo, Error> {
         let mut i = sys::PtMultiInfo::default();

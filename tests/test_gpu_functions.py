@@ -540,6 +540,28 @@ def test_multi_gpu_entry_with_one_device_over_rccl(pt, gpu_ctx):
         m.set_threads(False)
         lin, rgba = m.render_host(cam, pt.default_params(spp=6, band_rows=3))
         assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8)
+        # the exchange by copies (pt_multi_set_exchange: one DMA copy per device where the default form runs ncclGather), switched
+        # on an object that has frames behind it, in both thread modes, frames posted back to back -- more of them than the ring of
+        # send buffers holds -- and switched back: every frame the same bits
+        frames_before = m.info().frames
+        m.set_exchange("copy")
+        assert m.info().exchange == pt._lib.PT_EXCHANGE_COPY
+        for threads in (False, True):
+            m.set_threads(threads)
+            outs = [(torch.zeros((117, 200, 3), dtype=torch.float32, device=dev), torch.zeros((117, 200, 4), dtype=torch.uint8, device=dev)) for _ in range(11)]
+            for k, (lin_d, rgba_d) in enumerate(outs):
+                m.render_into(cam, pt.default_params(spp=6, band_rows=[7, 0, 64][k % 3]), lin_d.data_ptr(), rgba_d.data_ptr())
+            m.sync()
+            for lin_d, rgba_d in outs:
+                assert np.array_equal(lin_d.cpu().numpy(), ref) and np.array_equal(rgba_d.cpu().numpy(), ref8)
+        assert m.info().frames == frames_before + 22
+        m.set_threads(False)
+        m.set_exchange("rccl")
+        assert m.info().exchange == pt._lib.PT_EXCHANGE_RCCL
+        lin, rgba = m.render_host(cam, pt.default_params(spp=6, band_rows=5))
+        assert np.array_equal(lin, ref) and np.array_equal(rgba, ref8)
+        with pytest.raises(pt._lib.PtError, match="unknown mode"):
+            pt._lib.check(pt._lib.lib().pt_multi_set_exchange(m._h, 7))
     finally:
         m.close()
     lin, rgba = pt.render_multi([0], cam, objs, prm)
