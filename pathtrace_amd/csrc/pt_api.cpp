@@ -91,6 +91,15 @@ constexpr uint32_t kLaneGrid24 = PT_LANE_GRID24;      // core of a launch that o
 #endif
 constexpr uint32_t kLaneGrid24Split = PT_LANE_GRID24_SPLIT;   // ... k_paths_regen_split (5 workgroups per CU): C1 7.26 ms per step at 11, 7.13 at 12, 7.18 at 13
 constexpr int kLanes = PT_LANES;        // streams the regenerating launches of consecutive batches take in turn (2 or 3)
+// Buffer sets (sample buffer + launch counters) the lanes' launches rotate through: launch k waits for the resolve of launch
+// k - kSets.  With three, launch k + 3 waits for resolve k, which gets few wave slots beside the resident launches (146 us of work
+// take ~0.9 ms).  A fourth set, so that it need not, was measured and LOSES: the resolve then competes with one more pending launch
+// (C2 5.67 -> 6.1 ms per step, C1 7.15 -> 7.3; profiles/r04/ab_four_buffer_sets.txt).
+#ifndef PT_SETS
+#define PT_SETS 3
+#endif
+constexpr int kSets = PT_SETS;          // 3 or 4
+static_assert(kSets >= 3 && kSets <= 4, "PT_SETS: 3 or 4");
 constexpr uint32_t kStatsWords = 32;            // 16 x u64 at the front of the counter buffer: 8 render statistics, 8 words for measurement builds (PT_DRAIN_TIMING)
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
 #ifndef PT_SPLIT_BY_DEFAULT
@@ -182,10 +191,10 @@ struct PtContext {
     // ... and THREE buffer sets (sample buffer + launch counters) taken in turn: a resolve cannot run beside a resident
     // regenerating launch (it gets no wave slots until that launch runs dry: measured), so the resolve of batch k only
     // runs while batch k + 1 drains -- and batch k + 2's launch, which starts at that moment too, must not wait for it
-    hipEvent_t set_free[3] = {nullptr, nullptr, nullptr};
-    bool set_used[3] = {false, false, false};
+    hipEvent_t set_free[kSets] = {};
+    bool set_used[kSets] = {};
     uint32_t set_next = 0;
-    DevBuf<ptk::Rgb> lsamp3;
+    DevBuf<ptk::Rgb> lsamp3, lsamp4;
     uint32_t lane_next = 0;
     DevBuf<float4> cqueue[4];
     DevBuf<float4> caux, csray[2];    // ... and, for accel = 1, its own staged-pass scratch
@@ -205,7 +214,7 @@ struct PtContext {
     // counters of batch parity 0, 1 are zero (the resolve of the batch that used them last cleared them) -- a render
     // then needs no memset in the stream
     bool stats_clean = false;
-    bool counters_clean[3] = {false, false, false};
+    bool counters_clean[kSets] = {};
     uint32_t regen_occ[2][2][2] = {};          // cached occupancy query [exact_math][integrator][split] of this scene (0: not asked yet)
     uint32_t profiled_batches = 0;             // event slots (launch begin / end pairs) in use since the statistics were last collected
     std::vector<uint32_t> primary_events;      // slots of the level-0 launches
@@ -404,7 +413,7 @@ int pt_context_create(int device, PtContext** out) {
             delete c;
             return fail(PT_ERR_HIP, "lane stream / event creation failed");
         }
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < kSets; ++k)
         if (hipEventCreateWithFlags(&c->set_free[k], hipEventDisableTiming) != hipSuccess) {
             delete c;
             return fail(PT_ERR_HIP, "hipEventCreate failed");
@@ -442,7 +451,7 @@ int pt_context_destroy(PtContext* c) {
     for (auto& par : c->ovf) for (auto& q : par) for (auto& b : q) b.release();
     for (auto& b : c->cqueue) b.release();
     c->caux.release(); c->csray[0].release(); c->csray[1].release();
-    c->lsamp2.release(); c->lsamp3.release();
+    c->lsamp2.release(); c->lsamp3.release(); c->lsamp4.release();
     for (int k = 0; k < 2; ++k) {
         if (c->ev_l0[k]) (void)hipEventDestroy(c->ev_l0[k]);
         if (c->ev_resolved[k]) (void)hipEventDestroy(c->ev_resolved[k]);
@@ -454,7 +463,7 @@ int pt_context_destroy(PtContext* c) {
 
         if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
     }
-    for (int k = 0; k < 3; ++k) if (c->set_free[k]) (void)hipEventDestroy(c->set_free[k]);
+    for (int k = 0; k < kSets; ++k) if (c->set_free[k]) (void)hipEventDestroy(c->set_free[k]);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     c->xchg.release();
     c->ovf_count.release();
@@ -804,7 +813,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (overlap && hand_off && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
                                               (rc = c->csray[1].ensure(q_slots_cont))))
         return rc;
-    if ((rc = c->ovf_count.ensure(kStatsWords + 3 * kCountStride))) return rc;   // [render statistics | launch counters of buffer set 0 | 1 | 2]
+    if ((rc = c->ovf_count.ensure(kStatsWords + kSets * kCountStride))) return rc;   // [render statistics | launch counters of buffer set 0 | 1 | ...]
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
             for (int k = 0; k < 4; ++k)
@@ -854,7 +863,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         HIP_TRY(hipEventRecord(c->ev_begin, st));
         lanes_wait_pre = true;          // (the statistics' clearing -- here or at their collection -- is on that stream)
     }
-    for (int par = 0; par < (lanes ? 3 : two_sets ? 2 : 1); ++par)
+    for (int par = 0; par < (lanes ? kSets : two_sets ? 2 : 1); ++par)
         if (launch_words && !c->counters_clean[par]) {
             HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords + kCountStride * par, 0, kCountStride * sizeof(uint32_t), st));
             c->counters_clean[par] = true;
@@ -877,10 +886,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         int par = overlap ? (int)(batch & 1u) : 0;                // buffer set of this batch
         int lane = 0;                                             // ... and, with lanes, the stream its launch goes to
         if (lanes) {
-            par = (int)c->set_next; c->set_next = (c->set_next + 1u) % 3u;
+            par = (int)c->set_next; c->set_next = (c->set_next + 1u) % (uint32_t)kSets;
             lane = (int)c->lane_next; c->lane_next = (c->lane_next + 1u) % (uint32_t)kLanes;
         }
-        DevBuf<ptk::Rgb>& lsamp_buf = par == 2 ? c->lsamp3 : par ? c->lsamp2 : c->lsamp;
+        DevBuf<ptk::Rgb>& lsamp_buf = par == 3 ? c->lsamp4 : par == 2 ? c->lsamp3 : par ? c->lsamp2 : c->lsamp;
         if (lanes && (rc = lsamp_buf.ensure(n_paths_max))) return rc;
         ptk::Rgb* const lsamp_b = lsamp_buf.p;
         a.s_base = prm->spp_offset + s0;
@@ -898,7 +907,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 // this lane's stream: behind the resolve that read the lane's sample buffer last (two batches ago), and
                 // behind this call's fills on the caller's stream, if any -- not behind the caller's stream as such
                 ls = c->lane_stream[lane];
-                if (c->set_used[par]) HIP_TRY(hipStreamWaitEvent(ls, c->set_free[par], 0));      // (the resolve of three batches ago)
+                if (c->set_used[par]) HIP_TRY(hipStreamWaitEvent(ls, c->set_free[par], 0));      // (the resolve of kSets batches ago)
                 if (lanes_wait_pre && !lane_waited_pre[lane]) { HIP_TRY(hipStreamWaitEvent(ls, c->ev_pre, 0)); lane_waited_pre[lane] = true; }
                 // ... and not before the other lane's launch has been handed to the device: two launches that become
                 // ready at the same moment would share the device from the start and run dry together
