@@ -273,8 +273,7 @@ def main(argv=None):
         ctx = pt.Context(dev_index)
         ctx.upload(objs)
         ctx.set_tuning(**tuning)
-        if not os.environ.get("PT_BENCH_OWN_STREAM"):
-            ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         rows = pt.tile_rows(HEIGHT, band_rows, rank, world)
     lin = torch.empty((rows, WIDTH, 3), dtype=torch.float32, device=dev)
     rgba = torch.empty((rows, WIDTH, 4), dtype=torch.uint8, device=dev)
