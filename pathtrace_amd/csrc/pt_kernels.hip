@@ -831,6 +831,9 @@ constexpr uint32_t kRegenBlock = PT_REGEN_BLOCK;
 #ifndef PT_RING_LAZY
 #define PT_RING_LAZY 0
 #endif
+#ifndef PT_RESOLVE_UNROLL
+#define PT_RESOLVE_UNROLL 4     // k_resolve: samples whose loads are in flight together (32 VGPRs: what is free beside six 80-VGPR waves;
+#endif                          // 8 -> 56 VGPRs and C1 1.3 % slower; a raised wave priority: nothing.  profiles/r04/ab_resolve_variants.txt)
 #ifndef PT_DRAIN_MAIL
 #define PT_DRAIN_MAIL 0      // measured (round 4): N = 1 5.96 -> 6.17 ms (4 spilled dwords, the per-iteration checks), one rank's share at 8 ranks
 #endif                       // 0.955 -> 0.975 ms: pooling a workgroup's last paths in one wave buys nothing -- kept as a measurement variant
@@ -1896,7 +1899,19 @@ __global__ void __launch_bounds__(kBlock) k_resolve(ResolveArgs a) {
     if (p >= a.np) return;
     double r = 0.0, g = 0.0, b = 0.0;
     if (a.load_film) { r = a.film[3 * (size_t)p]; g = a.film[3 * (size_t)p + 1]; b = a.film[3 * (size_t)p + 2]; }
-    for (uint32_t s = 0; s < a.nb; ++s) {
+    uint32_t s = 0;
+#if PT_RESOLVE_UNROLL > 1
+    // several samples' loads in flight before the (ordered) additions: beside resident path-kernel waves a resolve wave gets few
+    // issue slots, and every exposed memory round trip counts
+    for (; s + PT_RESOLVE_UNROLL <= a.nb; s += PT_RESOLVE_UNROLL) {
+        Rgb v[PT_RESOLVE_UNROLL];
+#pragma unroll
+        for (int k = 0; k < PT_RESOLVE_UNROLL; ++k) v[k] = a.lsamp[(size_t)(s + k) * a.np + p];
+#pragma unroll
+        for (int k = 0; k < PT_RESOLVE_UNROLL; ++k) { r += (double)v[k].r; g += (double)v[k].g; b += (double)v[k].b; }
+    }
+#endif
+    for (; s < a.nb; ++s) {
         const Rgb v = a.lsamp[(size_t)s * a.np + p];
         r += (double)v.r; g += (double)v.g; b += (double)v.b;                     // world.rs:311
     }
