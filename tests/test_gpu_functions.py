@@ -750,6 +750,20 @@ def test_streamed_film_exchange_over_rccl_keeps_every_frame(pt):
         ring = FilmGather.RING_MAX
         assert len(set(ptrs[:ring])) == ring and ptrs[ring:2 * ring] == ptrs[:ring] and ptrs[2 * ring] == ptrs[0]
         ctx.sync()
+        # the forms that pack two existing planes (start / the blocking call) and the one-call entry of the per-process form
+        from pathtrace_amd.dist import render_distributed
+        fg2 = FilmGather(H, W, band, 0, 1, dev, always_collective=True)
+        for k in (3, 11):
+            fg2.start(ref[k][0], ref[k][1])
+        lin, rgba = fg2.finish()
+        torch.cuda.current_stream(dev).synchronize()
+        assert torch.equal(lin.view(torch.int32), ref[11][0].view(torch.int32)) and torch.equal(rgba, ref[11][1])
+        lin, rgba = fg2(ref[5][0], ref[5][1])
+        torch.cuda.current_stream(dev).synchronize()
+        assert torch.equal(lin.view(torch.int32), ref[5][0].view(torch.int32)) and torch.equal(rgba, ref[5][1])
+        lin, rgba = render_distributed(ctx, cam, pt.default_params(spp=8, spp_offset=8 * 7), 0, 1, band_rows=band)
+        torch.cuda.current_stream(dev).synchronize()
+        assert torch.equal(lin.view(torch.int32), ref[7][0].view(torch.int32)) and torch.equal(rgba, ref[7][1])
     finally:
         if ctx is not None:
             ctx.set_stream(None)

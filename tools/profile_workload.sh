@@ -14,7 +14,8 @@ python3 $ARGS > $OUT/bench_plain.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json
 # the same command with --in-order under the kernel trace: every launch on its own, so that the AVERAGE of the dominant kernel in
 # the --stats summary is a launch time too (in the default command's summary the timed steps' dispatches overlap and last 2-3 periods)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_in_order -- python3 $ARGS --in-order > $OUT/bench_trace_in_order.json
+# (20 steps like the driver's run: the first launches of a process run at clocks that are still ramping up)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_in_order -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-order $* > $OUT/bench_trace_in_order.json
 # counter passes: every launch in order and full size (--in-order), like the launches bench.py takes its launch time from -- a counter
 # pass serialises the kernels anyway, and an overlapping launch run alone would work with its core workgroups only (pt_api.cpp, lanes)
 ARGS="$ARGS --in-order"

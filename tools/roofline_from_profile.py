@@ -39,7 +39,7 @@ overlapped = [x for x in allv if x not in alone]
 io = []
 for f in glob.glob(f"{d}/trace_in_order/**/*kernel_trace.csv", recursive=True):
     rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if short(r["Kernel_Name"]) == dom)
-    io += [x[1] for x in rows[1:]]
+    io += [x[1] for x in rows[len(rows) // 5:]]          # not the warm-up steps (5 of 25: clocks still ramping up)
 
 # counters: per-dispatch average for the dominant kernel
 cnt = collections.defaultdict(float)
@@ -59,7 +59,7 @@ out = {
     "avg_launch_ms_kernel_trace": avg_ns / 1e6,
     "avg_launch_note": "in-order dispatches of the dominant kernel: bench.py's three event-timed steps after the timed region (all but the warm-up dispatch with --in-order)",
     "avg_launch_ms_in_order_run": (sum(io) / len(io) / 1e6) if io else None,
-    "in_order_run_note": "trace_in_order/: the same command with --in-order (every launch on its own): all dispatches of the kernel but the warm-up one; the average of the --stats summary there is a launch time",
+    "in_order_run_note": "trace_in_order/: the same command with --in-order (every launch on its own): the dispatches of its 20 timed steps; the average of the --stats summary there is a launch time",
     "overlapping_dispatches": len(overlapped),
     "overlapping_dispatches_period_ms": ((max(x[0] + x[1] for x in overlapped) - min(x[0] for x in overlapped)) / len(overlapped) / 1e6) if overlapped else None,
     "overlapping_dispatches_avg_trace_duration_ms": (sum(x[1] for x in overlapped) / len(overlapped) / 1e6) if overlapped else None,
