@@ -13,13 +13,16 @@
 // streams: its context's (the render: regenerating launches on the context's lanes, the resolve that writes the send buffer)
 // and an EXCHANGE stream (its ncclGather call; on the root also the row permutation), and a ring of send buffers between them
 // (kSendSlots) -- frame k's resolve records `ready` for the exchange stream, its gather records `sent` for the resolve of
-// frame k + kSendSlots.  The gather is kept out of the render stream because its kernel can be LATE: with three launches of
-// a device in flight (pt_api.cpp: lanes) one regenerating dispatch is always waiting for wave slots, and while it waits the
-// dispatches of other queues queue up behind it -- RCCL's kernel (one workgroup, ~20 us of work) gets through when a launch
-// ENDS, up to a launch later (profiles/r04/reserved_cus_rejected.txt: not for want of free compute units).  In the render
-// stream that wait held back the next frame's resolve and with it the lanes (6.10 ms per C2 frame on one device against 5.77
-// without the gather); behind a ring of send buffers nobody waits for it.  On the root the receive buffer is written by a
-// gather that follows the previous frame's row permutation in the exchange stream.  By default the calling thread enqueues the devices in turn and the n gather calls form one ncclGroupStart/End;
+// frame k + kSendSlots.  The gather is kept out of the render stream because its kernel can be LATE: RCCL's kernel is ONE workgroup
+// of 4 x 132 VGPRs (~20 us of work), and with three regenerating launches of a device in flight (pt_api.cpp: lanes; six 80-VGPR
+// waves per SIMD, a pending launch taking every slot that frees) it is not placed until they run out of work -- measured: 10-30 ms
+// (profiles/r04/gather_kernel_beside_lanes.txt; not for want of free compute units, priority or scratch:
+// reserved_cus_rejected.txt).  In the render stream that wait held back the next frame's resolve and with it the lanes: one
+// pipeline drain per frame (6.10 ms per C2 frame on one device against 5.77 without the gather).  Behind the ring the render
+// stream waits for a gather only when it wants that gather's send buffer back, and the gathers of several frames complete in one
+// stall.  pt_multi_set_exchange(m, PT_EXCHANGE_COPY) takes the kernel out altogether (one DMA copy per device).  On the root the
+// receive buffer is written by a gather that follows the previous frame's row permutation in the exchange stream.
+// By default the calling thread enqueues the devices in turn and the n gather calls form one ncclGroupStart/End;
 // pt_multi_set_threads(m, 1) gives every device its own host thread instead (pt_feeder.h: its launches, its ncclGather call
 // on its own communicator -- the one-thread-per-device use of RCCL), the call then returns as soon as the frame is posted
 // and pt_multi_sync() waits for the threads, then for the streams.
