@@ -14,6 +14,7 @@ tests/test_gpu_quadrature.py does this for the integrator (MIS weights, roulette
   (c) Lambertian and OrenNayar bsdf_pdf (material.rs:86-91, 221-265, coefficients :182-193) and their cosine-weighted sampler
       (material.rs:93-119): values against the formulas (the reference's atan2 form of cos(phi_i - phi_o), not the kernels' atan2-free
       one), draw for draw directions, and the energy integral of the Lambertian = albedo.
+  (d) Camera::new / Camera::look_at / get_ray_with_offset (camera.rs:50-147) as World::render_pixel calls it (world.rs:297-299).
 
 Tolerances are f32 ones against f64 (1e-4 relative, looser where a formula is ill-conditioned -- stated at the assertion).
 """
@@ -303,3 +304,55 @@ def test_cosine_weighted_sampler_draw_for_draw_and_lambertian_energy(pt, gpu_ctx
         if obj == 0:
             w = s[:, 3:6] * s[:, 7:8] / s[:, 6:7]                                               # f cos / pdf = albedo, sample by sample
             assert np.abs(w - albedo).max() <= 1e-4
+
+
+# ------------------------------------------------------------------ (d) camera
+def _camera_new(origin, width, height, screen_distance, fov_degrees):
+    """Camera::new, camera.rs:50-82"""
+    origin = np.asarray(origin, dtype=np.float64)
+    vh = 2.0 * np.tan(np.radians(fov_degrees) / 2.0) * screen_distance
+    vw = vh * (width / height)
+    hor, ver = np.array([vw, 0.0, 0.0]), np.array([0.0, vh, 0.0])
+    return origin, origin - hor / 2.0 - ver / 2.0 - np.array([0.0, 0.0, screen_distance]), hor, ver
+
+
+def _camera_look_at(origin, target, up, width, height, fov_degrees):
+    """Camera::look_at, camera.rs:94-130"""
+    origin, target, up = (np.asarray(a, dtype=np.float64) for a in (origin, target, up))
+    w = _norm(origin - target)
+    u = _norm(np.cross(up, w))
+    v = np.cross(w, u)
+    vh = 2.0 * np.tan(np.radians(fov_degrees) / 2.0)
+    vw = vh * (width / height)
+    hor, ver = u * vw, v * vh
+    return origin, origin - hor / 2.0 - ver / 2.0 - w, hor, ver
+
+
+@pytest.mark.parametrize("kind", ["new", "look_at"])
+def test_camera_rays_against_camera_rs(pt, gpu_ctx, kind):
+    """Camera::new / look_at and get_ray_with_offset (camera.rs:139-147) as World::render_pixel calls it (world.rs:297-299: film row
+    y looks through camera row HEIGHT - 1 - y): the host-side constructors and the device's ray against the formulas, with the
+    jitter the device reports for the sample."""
+    W, H = 317, 201
+    if kind == "new":
+        cam = pt.camera_new(origin=(0.1, -0.2, 2.5), width=W, height=H, screen_distance=1.3, fov_degrees=41.0)
+        org, llc, hor, ver = _camera_new((0.1, -0.2, 2.5), W, H, 1.3, 41.0)
+    else:
+        cam = pt.camera_look_at((1.0, 0.7, 2.0), (0.0, -0.1, -2.0), (0.1, 1.0, 0.0), W, H, 33.0)
+        org, llc, hor, ver = _camera_look_at((1.0, 0.7, 2.0), (0.0, -0.1, -2.0), (0.1, 1.0, 0.0), W, H, 33.0)
+    for got, want in ((cam.origin, org), (cam.lower_left, llc), (cam.horizontal, hor), (cam.vertical, ver)):
+        assert np.abs(np.array(list(got)) - want).max() <= 1e-12
+    gpu_ctx.upload(pt.builtin_scene(2))
+    rng = np.random.default_rng(9)
+    n = 50_000
+    xys = np.stack([rng.integers(0, W, n), rng.integers(0, H, n), rng.integers(0, 4096, n)], 1).astype(np.uint32)
+    xys[:4] = [[0, 0, 0], [W - 1, 0, 1], [0, H - 1, 2], [W - 1, H - 1, 3]]
+    out = gpu_ctx.debug_camera_rays(cam, xys).astype(np.float64)               # origin3, direction3, ox, oy
+    ox, oy = out[:, 6], out[:, 7]
+    assert (ox > 0).all() and (ox < 1).all() and (oy > 0).all() and (oy < 1).all()
+    assert abs(ox.mean() - 0.5) <= 5.0 / np.sqrt(12.0 * n) and abs(oy.mean() - 0.5) <= 5.0 / np.sqrt(12.0 * n)
+    u = (xys[:, 0] + ox) / (W - 1)                                            # camera.rs:140-141
+    v = ((H - 1 - xys[:, 1].astype(np.float64)) + oy) / (H - 1)               # world.rs:298
+    d = _norm(llc + hor * u[:, None] + ver * v[:, None] - org)                # camera.rs:143-146, Ray::new normalises (camera.rs:10-16)
+    assert np.abs(out[:, 0:3] - org).max() <= 1e-6
+    assert np.abs(out[:, 3:6] - d).max() <= 2e-6
