@@ -15,6 +15,7 @@ tests/test_gpu_quadrature.py does this for the integrator (MIS weights, roulette
       (material.rs:93-119): values against the formulas (the reference's atan2 form of cos(phi_i - phi_o), not the kernels' atan2-free
       one), draw for draw directions, and the energy integral of the Lambertian = albedo.
   (d) Camera::new / Camera::look_at / get_ray_with_offset (camera.rs:50-147) as World::render_pixel calls it (world.rs:297-299).
+  (e) World::sample_light_point (world.rs:251-267) over the light list of world.rs:213-225: pick, point, emission, pdf / n.
 
 Tolerances are f32 ones against f64 (1e-4 relative, looser where a formula is ill-conditioned -- stated at the assertion).
 """
@@ -356,3 +357,66 @@ def test_camera_rays_against_camera_rs(pt, gpu_ctx, kind):
     d = _norm(llc + hor * u[:, None] + ver * v[:, None] - org)                # camera.rs:143-146, Ray::new normalises (camera.rs:10-16)
     assert np.abs(out[:, 0:3] - org).max() <= 1e-6
     assert np.abs(out[:, 3:6] - d).max() <= 2e-6
+
+
+# ------------------------------------------------------------------ (e) World::sample_light_point
+def test_sample_light_point_against_world_rs(pt, gpu_ctx):
+    """World::sample_light_point (world.rs:251-267) over World::new's light list (world.rs:213-225: the objects whose emission is not
+    zero, in object order): which light an index word picks (uniformly: floor(u * n)), that light's own point sampling (shape.rs:106-131
+    for a sphere, :208-217 for a triangle) draw for draw, its emission, and pdf = pdf_shape / n."""
+    tri_a = [-0.3, 0.99, -2.3, 0.3, 0.99, -2.3, 0.3, 0.99, -1.7]
+    tri_b = [0.9, -0.2, -2.0, 0.9, 0.5, -2.4, 0.9, 0.4, -1.6]
+    sph = [-0.5, 0.3, -1.5, 0.2]
+    specs = [(SPH, [0.4, -0.6, -2.0, 0.4], LAMBERT, [0.7, 0.7, 0.7]),
+             (SPH, sph, EMISSIVE, [4.0, 3.0, 2.0]),
+             (TRI, [-1, -1, -3, 1, -1, -3, 0, 1, -3], LAMBERT, [0.5, 0.5, 0.5]),
+             (TRI, tri_a, EMISSIVE, [9.0, 9.0, 8.0]),
+             (SPH, [0.0, -0.9, -1.2, 0.1], EMISSIVE, [0.0, 0.0, 0.0]),       # emits nothing: not a light
+             (TRI, tri_b, EMISSIVE, [1.0, 2.0, 3.0])]
+    lights = [1, 3, 5]
+    gpu_ctx.upload(pt.make_objects(specs))
+    rng = np.random.default_rng(21)
+    n = 120_000
+    frm = np.array([0.1, -0.5, -1.9]) + rng.uniform(-0.2, 0.2, (n, 3))
+    words, uni = _uniforms(rng, n, 4)
+    out = gpu_ctx.debug_light_point(frm, words).astype(np.float64)          # point3, emission3, pdf, light object
+    pick = ((words[:, 0].astype(np.uint64) * 3) >> 32).astype(np.int64)
+    assert (out[:, 7].astype(np.int64) == np.array(lights)[pick]).all()
+    assert np.abs(np.bincount(pick, minlength=3) / n - 1.0 / 3.0).max() < 0.01
+    r1, r2 = uni[:, 1], uni[:, 2]
+    for k, obj in enumerate(lights):
+        m = pick == k
+        sv = np.asarray(specs[obj][1], dtype=np.float64)
+        assert np.abs(out[m, 3:6] - np.asarray(specs[obj][3])).max() == 0.0
+        f = frm[m]
+        if specs[obj][0] == SPH:
+            c, r = sv[:3], sv[3]
+            tc = c - f
+            d2 = (tc * tc).sum(-1)
+            cmax = np.sqrt(np.maximum(1.0 - r * r / d2, 0.0))
+            pdf_shape = 1.0 / (2.0 * np.pi * (1.0 - cmax))
+            ct = 1.0 - r1[m] + r1[m] * cmax
+            st = np.sqrt(np.maximum(1.0 - ct * ct, 0.0))
+            phi = 2.0 * np.pi * r2[m]
+            w = _norm(tc)
+            up = np.where((np.abs(w[:, 1]) > 0.999)[:, None], np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0]))
+            u = _norm(np.cross(up, w))
+            v = np.cross(w, u)
+            dr = _norm(u * (st * np.cos(phi))[:, None] + v * (st * np.sin(phi))[:, None] + w * ct[:, None])
+            oc = f - c
+            hb = (oc * dr).sum(-1)
+            disc = hb * hb - ((oc * oc).sum(-1) - r * r)
+            point = f + dr * (-hb - np.sqrt(np.maximum(disc, 0.0)))[:, None]
+            tol = 2e-4          # the root near the cone's rim is a small difference of two larger numbers
+        else:
+            v0, v1, v2 = sv[0:3], sv[3:6], sv[6:9]
+            s1 = np.sqrt(r1[m])
+            point = v0 + (v1 - v0) * (1.0 - s1)[:, None] + (v2 - v0) * (r2[m] * s1)[:, None]
+            nn = np.cross(v1 - v0, v2 - v0)
+            area = 0.5 * np.linalg.norm(nn)
+            to = point - f
+            dd = np.linalg.norm(to, axis=1)
+            pdf_shape = dd * dd / (area * np.abs((to / dd[:, None]) @ _norm(nn)))
+            tol = 1e-5
+        assert np.abs(out[m, 0:3] - point).max() <= tol, obj
+        assert np.abs(out[m, 6] / (pdf_shape / 3.0) - 1.0).max() <= 5e-4, obj       # world.rs:260
