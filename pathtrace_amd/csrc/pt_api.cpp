@@ -222,6 +222,7 @@ struct PtContext {
     uint32_t* h_posted = nullptr;              // host memory the device reads: number of the last lanes launch enqueued (BounceArgs.posted)
     uint32_t* d_posted = nullptr;              // ... its device address
     uint32_t lane_seq = 0;
+    bool stream_work_since_lanes = false;      // a render without lanes has been enqueued since the last one with (render_impl)
     bool bvh_failed = false;                   // the BVH builder refused this scene (depth): PT_ACCEL_AUTO stays with the scan
     // pixel-list entries (pt_render_pixels, pt_ray_color)
     DevBuf<uint2> pixel_list;
@@ -869,6 +870,13 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             c->counters_clean[par] = true;
             lanes_wait_pre = true;
         }
+    // A render that does NOT take the lanes (queue form, pixel lists, profiled or in-order renders) runs on the caller's stream and
+    // uses buffer sets 0 / 1 and their counters there.  Lane launches are ordered behind RESOLVES of lane launches only, so the
+    // first lanes render after such a render waits for the caller's stream as it stands now -- otherwise its launch could write
+    // the sample buffer a queued queue-form render has yet to resolve, or have its chunk counters cleared by that render's
+    // resolve (found by test_random_sequences_of_pipelined_renders_equal_isolated_renders: 3 % of a film's samples lost).
+    if (lanes && c->stream_work_since_lanes) lanes_wait_pre = true;
+    c->stream_work_since_lanes = !lanes;
     if (lanes && lanes_wait_pre) HIP_TRY(hipEventRecord(c->ev_pre, st));
     bool lane_waited_pre[kLanes] = {};
     uint32_t launches = 0;
