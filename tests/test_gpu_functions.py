@@ -632,6 +632,44 @@ def test_multi_gpu_entry_with_one_device_over_rccl(pt, gpu_ctx):
     pt._lib.lib().pt_shutdown()
 
 
+@pytest.mark.parametrize("form", ["rccl", "copy", "rccl-threads", "shared3", "shared3-threads"])
+def test_random_frame_sequences_through_the_multi_device_object(pt, gpu_ctx, form):
+    """Frames of random size, band height and sample count posted back to back through pt_multi_* -- growing and shrinking tiles
+    (re-allocation of the send ring and the receive buffer between frames in flight, a ring of a different length for a large
+    frame), more frames than the ring holds -- over the real ncclGather with the one device, the exchange by copies, host threads, and
+    three contexts sharing the device: every frame equals the plain render of the same job."""
+    import torch
+    rng = np.random.default_rng(len(form))
+    dev = torch.device("cuda", 0)
+    objs = pt.builtin_scene(2)
+    gpu_ctx.upload(objs)
+    jobs = []
+    for k in range(14):
+        W, H = [(96, 64), (200, 117), (512, 300), (33, 9), (640, 480)][int(rng.integers(0, 5))]
+        jobs.append((pt.camera_new(width=W, height=H), dict(spp=int(rng.choice([2, 4, 6])), spp_offset=int(rng.integers(0, 100)),
+                                                           band_rows=int(rng.choice([0, 1, 7, 32])))))
+    refs = []
+    for cam, kw in jobs:
+        lin, rgba = gpu_ctx.render(cam, pt.default_params(spp=kw["spp"], spp_offset=kw["spp_offset"]))
+        refs.append((lin.clone(), rgba.clone()))
+    m = pt.Multi([0, 0, 0], shared_device=0) if form.startswith("shared3") else pt.Multi([0])
+    try:
+        m.upload(objs)
+        if form == "copy":
+            m.set_exchange("copy")
+        if form.endswith("threads"):
+            m.set_threads(True)
+        outs = [(torch.zeros_like(a), torch.zeros_like(b)) for a, b in refs]
+        for (cam, kw), (lin_d, rgba_d) in zip(jobs, outs):
+            m.render_into(cam, pt.default_params(**kw), lin_d.data_ptr(), rgba_d.data_ptr())
+        m.sync()
+        for k, ((lin_d, rgba_d), (lin, rgba)) in enumerate(zip(outs, refs)):
+            assert torch_equal(lin_d.view(torch.int32), lin.view(torch.int32)) and torch_equal(rgba_d, rgba), (k, jobs[k][1])
+        assert m.stats().samples == sum(c.width * c.height * kw["spp"] for c, kw in jobs)
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("n", [2, 3, 8])
 def test_multi_gpu_partition_pack_unpack_for_n_devices(pt, gpu_ctx, n):
     """The band partition, the 16 B/pixel pack and the row permutation of pt_multi_* for n = 2, 3, 8 devices, emulated on
