@@ -200,7 +200,8 @@ int pt_context_destroy(PtContext* ctx);
 /* Run the library's kernels on a caller-owned hipStream_t (e.g. torch's current
  * stream) instead of the context's own (non-blocking) stream.  NULL restores the context's own
  * stream; PT_STREAM_LEGACY_DEFAULT names HIP's legacy default stream, whose handle is also 0
- * (torch's default stream): pass it when the render must be ordered against work queued there.   */
+ * (torch's default stream): pass it when the render must be ordered against work queued there.
+ * Renders already enqueued on the previous stream stay ahead: the new stream waits for it once.  */
 #define PT_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1)
 int pt_context_set_stream(PtContext* ctx, void* hip_stream);
 int pt_context_set_tuning(PtContext* ctx, const PtTuning* tuning);

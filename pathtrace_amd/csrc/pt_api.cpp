@@ -186,7 +186,7 @@ struct PtContext {
     // batches -- of one render or of renders enqueued back to back --, so that the launch of batch k + 1 fills the device
     // while the last waves of batch k run dry; the resolves stay in order on the caller's stream
     hipStream_t lane_stream[kLanes] = {};
-    hipEvent_t lane_done[kLanes] = {}, lane_begun[kLanes] = {}, ev_pre = nullptr;
+    hipEvent_t lane_done[kLanes] = {}, lane_begun[kLanes] = {}, ev_pre = nullptr, ev_switch = nullptr;
     bool lane_used[kLanes] = {};
     // ... and THREE buffer sets (sample buffer + launch counters) taken in turn: a resolve cannot run beside a resident
     // regenerating launch (it gets no wave slots until that launch runs dry: measured), so the resolve of batch k only
@@ -419,7 +419,8 @@ int pt_context_create(int device, PtContext** out) {
             delete c;
             return fail(PT_ERR_HIP, "hipEventCreate failed");
         }
-    if (hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail(PT_ERR_HIP, "hipEventCreate failed");
     }
@@ -466,6 +467,7 @@ int pt_context_destroy(PtContext* c) {
     }
     for (int k = 0; k < kSets; ++k) if (c->set_free[k]) (void)hipEventDestroy(c->set_free[k]);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
     c->xchg.release();
     c->ovf_count.release();
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
@@ -484,8 +486,16 @@ int pt_context_destroy(PtContext* c) {
 
 int pt_context_set_stream(PtContext* c, void* hip_stream) {
     if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
-    if (hip_stream == PT_STREAM_LEGACY_DEFAULT) c->stream = nullptr;      // HIP's legacy default stream (handle 0)
-    else c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t next = hip_stream == PT_STREAM_LEGACY_DEFAULT ? nullptr                       // HIP's legacy default stream (handle 0)
+                                                               : hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (next != c->stream && c->ev_switch) {
+        // The context's buffers (sample buffers, counters, film sums, statistics) are handed from render to render in the order of
+        // ONE stream: what is already enqueued on the old stream comes before anything the new one gets.
+        (void)hipSetDevice(c->device);
+        if (hipEventRecord(c->ev_switch, c->stream) == hipSuccess) (void)hipStreamWaitEvent(next, c->ev_switch, 0);
+        (void)hipGetLastError();
+    }
+    c->stream = next;
     return PT_OK;
 }
 

@@ -426,6 +426,34 @@ def test_random_sequences_of_pipelined_renders_equal_isolated_renders(pt, seed):
             c.close()
 
 
+def test_renders_keep_their_order_across_a_change_of_stream(pt):
+    """pt_context_set_stream while renders are in flight: the context hands its sample buffers, counters and statistics from
+    render to render in the order of one stream, so what is already enqueued on the old stream must stay ahead of what the new
+    one gets.  Six renders (queue form and regenerating form in turn) posted back to back, the stream changed before each one,
+    one synchronisation at the end: every film equals the job run alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = pt.Context(0)
+    try:
+        ctx.upload(pt.builtin_scene(2))
+        jobs = [(pt.camera_new(width=w, height=h), pt.default_params(spp=spp, spp_offset=7 * k))
+                for k, (w, h, spp) in enumerate([(400, 300, 8), (64, 64, 8), (512, 256, 4), (48, 32, 12), (320, 320, 6), (64, 48, 4)])]
+        refs = [tuple(t.clone() for t in ctx.render(cam, prm)) for cam, prm in jobs]
+        streams = [torch.cuda.Stream(dev) for _ in range(3)]
+        outs = [(torch.zeros_like(a), torch.zeros_like(b)) for a, b in refs]
+        ctx.sync()
+        for k, ((cam, prm), (lin_d, rgba_d)) in enumerate(zip(jobs, outs)):
+            ctx.set_stream(None if k == 3 else streams[k % 3].cuda_stream)
+            ctx.render_into(cam, prm, lin_d.data_ptr(), rgba_d.data_ptr())
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        for k, ((lin_d, rgba_d), (lin, rgba)) in enumerate(zip(outs, refs)):
+            assert torch_equal(lin_d.view(torch.int32), lin.view(torch.int32)) and torch_equal(rgba_d, rgba), k
+    finally:
+        ctx.set_stream(None)
+        ctx.close()
+
+
 def _oren_nayar_cornell(pt):
     """C2 with every Lambertian surface OrenNayar (material.rs:166-296), rough and smooth: a scene without Mirror
     surfaces, which takes the regenerating kernel compiled without the GGX code by default (round 3)."""
