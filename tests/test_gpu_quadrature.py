@@ -479,3 +479,50 @@ def test_furnace_a_convex_body_inside_a_sphere_light(pt, gpu_ctx, integrator, ai
     # a ray that misses the body sees the enclosure itself
     mean, sem = _gpu_mean(gpu_ctx, pt, origin, np.array([2.0, 1.5, -2.0]), n=1 << 12, integrator=integrator)
     assert np.abs(mean - le).max() <= 1e-5
+
+
+def _oren_nayar_albedo(sigma, i, n, m=1500):
+    """Int f_OrenNayar(i, o) cos_o d omega_o / rho for incoming direction i (pointing away from the surface), material.rs:221-265"""
+    s2 = sigma * sigma
+    A, B = 1.0 - 0.5 * s2 / (s2 + 0.33), 0.45 * s2 / (s2 + 0.09)
+    up = np.array([1.0, 0.0, 0.0]) if abs(n[1]) > 0.999 else np.array([0.0, 1.0, 0.0])
+    t = _norm(np.cross(up, n))
+    b = np.cross(n, t)
+    u = (np.arange(m) + 0.5) / m
+    th, ph = np.meshgrid(0.5 * np.pi * u, 2.0 * np.pi * u, indexing="ij")
+    co, so = np.cos(th), np.sin(th)
+    ci = max(float(i @ n), 0.0)
+    si = np.sqrt(max(1.0 - ci * ci, 0.0))
+    phi_i = np.arctan2(i @ b, i @ t)
+    cphi = np.maximum(np.cos(phi_i - ph), 0.0)
+    first = ci > co
+    tan_beta = np.where(first, si / ci if ci > 1e-6 else 0.0, np.where(co > 1e-6, so / np.maximum(co, 1e-300), 0.0))
+    sin_alpha = np.where(first, so, si)
+    f = (A + B * cphi * sin_alpha * tan_beta) / np.pi
+    return float((f * co * so * (0.5 * np.pi / m) * (2.0 * np.pi / m)).sum())
+
+
+@pytest.mark.parametrize("min_depth", [4, 0], ids=["no roulette", "roulette from the first vertex"])
+@pytest.mark.parametrize("sigma", [0.0, 0.6, 1.0])
+def test_furnace_oren_nayar_body_brdf_only(pt, gpu_ctx, sigma, min_depth):
+    """The furnace with an OrenNayar body (material.rs:166-296) under BrdfOnlyStrategy: the radiance sent back is Le times the
+    directional albedo  Int f(i, o) cos_o d omega_o  of the reference's BRDF for the view direction -- by quadrature of the formula --,
+    with and without Russian roulette at the first vertex (rendering.rs:246-262: survivors are divided by the survival
+    probability, so the mean must not move).  sigma = 0 is the Lambertian value rho."""
+    le = np.array([1.7, 1.1, 0.6])
+    rho = np.array([0.8, 0.5, 0.2])
+    c_body, r_body = np.array([0.0, 0.0, -2.0]), 0.5
+    objs = pt.make_objects([(SPH, [0.1, -0.2, -0.3, 9.0], EMISSIVE, list(le)),
+                            (SPH, list(c_body) + [r_body], 3, list(rho) + [sigma])])
+    gpu_ctx.upload(objs)
+    origin, target = np.array([0.0, 0.0, 1.0]), np.array([0.33, -0.18, -2.0])
+    d = _norm(target - origin)
+    oc = origin - c_body
+    hb = oc @ d
+    x = origin + (-hb - np.sqrt(hb * hb - (oc @ oc - r_body * r_body))) * d
+    n = (x - c_body) / r_body
+    k = _oren_nayar_albedo(sigma, -d, n)
+    if sigma == 0.0:
+        assert abs(k - 1.0) < 1e-5
+    mean, sem = _gpu_mean(gpu_ctx, pt, origin, target, integrator=1, min_depth=min_depth)
+    _check(mean, sem, rho * le * k, f"OrenNayar furnace sigma {sigma} min_depth {min_depth}")
