@@ -526,3 +526,32 @@ def test_furnace_oren_nayar_body_brdf_only(pt, gpu_ctx, sigma, min_depth):
         assert abs(k - 1.0) < 1e-5
     mean, sem = _gpu_mean(gpu_ctx, pt, origin, target, integrator=1, min_depth=min_depth)
     _check(mean, sem, rho * le * k, f"OrenNayar furnace sigma {sigma} min_depth {min_depth}")
+
+
+@pytest.mark.parametrize("aim", [(0.0, 0.0), (0.36, -0.2)], ids=["centre", "oblique"])
+def test_furnace_metal_body_brdf_only(pt, gpu_ctx, aim):
+    """The furnace with a GGX metal body (mirror.rs) under BrdfOnlyStrategy: one vertex on the body, the sampled direction then meets
+    the enclosure, so the radiance is Le * E[f cos / pdf] over Mirror::bsdf_pdf_sample's own draws -- evaluated here with the numpy
+    restatement of the sampler (_ggx_sample, mirror.rs:200-305) on an independent set of uniforms; the integrator hands the material
+    eta_ratio = 1 / ior on a front face (rendering.rs:20-25).  Pins how the integrator applies the sampler's weight (the cosine, the
+    F = 1 of a metal's sampled reflection, a failed sample = nothing); 4 sigma of both Monte-Carlo errors together."""
+    rough, color, metallic, ior = GGX_MATS["metal"]
+    le = np.array([1.7, 1.1, 0.6])
+    c_body, r_body = np.array([0.0, 0.0, -2.0]), 0.5
+    gpu_ctx.upload(pt.make_objects([(SPH, [0.1, -0.2, -0.3, 9.0], EMISSIVE, list(le)),
+                                    (SPH, list(c_body) + [r_body], MIRROR, [rough] + color + [metallic, ior])]))
+    origin, target = np.array([0.0, 0.0, 1.0]), np.array([aim[0], aim[1], -2.0])
+    d = _norm(target - origin)
+    oc = origin - c_body
+    hb = oc @ d
+    x = origin + (-hb - np.sqrt(hb * hb - (oc @ oc - r_body * r_body))) * d
+    n = (x - c_body) / r_body
+    rng = np.random.default_rng(5)
+    k = 1 << 20
+    _, f, pdf, cosv = _ggx_sample(-d, n, rough, color, metallic, ior, 1.0 / ior, rng.random(k), rng.random(k), rng.random(k))
+    w = f * (cosv / pdf)[:, None]
+    want, want_sem = w.mean(0), w.std(0, ddof=1) / np.sqrt(k)
+    mean, sem = _gpu_mean(gpu_ctx, pt, origin, target, integrator=1)
+    tol = 4.0 * np.sqrt(sem ** 2 + (le * want_sem) ** 2) + 2e-4 * le * want
+    assert np.all(np.abs(mean - le * want) <= tol), (mean, le * want, (mean - le * want) / np.sqrt(sem ** 2 + (le * want_sem) ** 2))
+    assert np.all(want > 0.3) and np.all(want < 1.0)
