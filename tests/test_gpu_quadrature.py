@@ -22,6 +22,13 @@ tests are the statement that can be made without either: the quirks of the refer
         the squared index); and the sampler's mean weight E[f cos / pdf] against Int f_eval cos dw for the metal, with F = 1
         on both sides -- a metal's sampled reflection carries F = 1 instead of Schlick's coloured F (mirror.rs:225-231).
         For glass the reference's sampler and eval are not consistent with each other (see the test): printed, not asserted.
+  (iv)  Furnace tests -- a convex body inside a uniformly emitting sphere must send back albedo * Le: BrdfOnlyStrategy does (Lambertian,
+        OrenNayar by its directional albedo, GGX metal by its sampler's mean weight, with and without roulette); MisStrategy loses
+        25-45 %, because the reference samples a sphere light seen from INSIDE over half of the directions only (shape.rs:98-136) while
+        the look-ahead pdf claims all of them -- a quirk beyond SURVEY's Q1-Q10, reproduced and pinned by quadrature.
+  (v)   An integrating sphere (Lambertian sphere lit by a small sphere at its centre): the wall radiance with ALL orders of
+        interreflection is rho Le s / (1 - rho (1 - s)); MIS without roulette and BRDF-only with roulette return it, MIS with the
+        reference's roulette returns the value the Q1 recursion predicts (up to 12 % less).
 """
 import numpy as np
 import pytest
@@ -555,3 +562,62 @@ def test_furnace_metal_body_brdf_only(pt, gpu_ctx, aim):
     tol = 4.0 * np.sqrt(sem ** 2 + (le * want_sem) ** 2) + 2e-4 * le * want
     assert np.all(np.abs(mean - le * want) <= tol), (mean, le * want, (mean - le * want) / np.sqrt(sem ** 2 + (le * want_sem) ** 2))
     assert np.all(want > 0.3) and np.all(want < 1.0)
+
+
+# ------------------------------------------------------------------ (v) an integrating sphere: infinitely many bounces in closed form
+def _direct_split(s, m=200_000):
+    """The one-bounce radiance rho * Le * s of a wall point under the central sphere light, split into its NEE part and its
+    BSDF-sampled part by the MIS weights of rendering.rs:73,117 (one light: they sum to 1), as fractions of rho * Le.
+    The light fills the cone of half-angle asin(sqrt s) about the normal; p_l = 1 / (2 pi (1 - cos_max)), p_b = cos / pi."""
+    cmax = np.sqrt(1.0 - s)
+    th = (np.arange(m) + 0.5) / m * np.arccos(cmax)
+    dth = np.arccos(cmax) / m
+    p_l, p_b = 1.0 / (2.0 * np.pi * (1.0 - cmax)), np.cos(th) / np.pi
+    ring = np.cos(th) / np.pi * 2.0 * np.pi * np.sin(th) * dth
+    return float((ring * p_l / (p_l + p_b)).sum()), float((ring * p_b / (p_b + p_l)).sum())
+
+
+@pytest.mark.parametrize("case", ["mis, no roulette", "mis, roulette from depth 4 (Q1)", "brdf only, roulette from depth 4", "brdf only, roulette from depth 0"])
+def test_integrating_sphere_every_bounce_in_closed_form(pt, gpu_ctx, case):
+    """A Lambertian sphere of radius R seen from inside, lit by a small emissive sphere of radius r at its centre.  By symmetry the
+    wall's radiance L is the same everywhere, and a wall point receives  pi Le s  from the light (s = (r / R)^2: a sphere of radiance
+    Le centred on the normal) plus  pi (1 - s) L  from the rest of the wall (the light hides the cone it fills):
+        L = rho (Le s + (1 - s) L)   =>   L = rho Le s / (1 - rho (1 - s))
+    -- all orders of interreflection, exactly.  What the estimators make of it:
+      * MisStrategy without roulette (min_depth = max_depth = 50; the 50 bounces carry all but rho^50 of it): L.
+      * BrdfOnlyStrategy with roulette: L too -- a survivor is divided by its survival probability (rendering.rs:237-262).
+      * MisStrategy WITH roulette (the reference's defaults): less.  A path killed at a vertex returns zero (rendering.rs:100-102),
+        which drops that vertex's NEE term as well: with D_nee + D_bsdf = rho Le s the direct light split by the MIS
+        weights, and rr_d = min(1, lum(T_d rho)) the survival probability at depth d >= 4 (T_{d+1} = T_d rho / rr_d),
+            E_d = rr_d D_nee + D_bsdf + rho (1 - s) E_{d+1}.
+    2^20 streams per case, 4 sigma; the MIS roulette case must also EXCLUDE the unbiased L."""
+    R, r = 2.0, 0.3
+    le = np.array([20.0, 14.0, 9.0])
+    rho = np.array([0.7, 0.5, 0.25])
+    s = (r / R) ** 2
+    gpu_ctx.upload(pt.make_objects([(SPH, [0, 0, 0, R], LAMBERT, list(rho)), (SPH, [0, 0, 0, r], EMISSIVE, list(le))]))
+    origin = np.array([0.6, 0.3, 0.2])
+    target = origin + np.array([1.0, 0.4, 0.3])
+    L = rho * le * s / (1.0 - rho * (1.0 - s))
+    mis = case.startswith("mis")
+    min_depth = 50 if "no roulette" in case else 0 if "depth 0" in case else 4
+    want = L
+    if mis and min_depth == 4:
+        d_nee, d_bsdf = _direct_split(s)
+        assert abs(d_nee + d_bsdf - s) < 1e-6 * s
+        T, rr = np.ones(3), []
+        for d in range(90):                                    # T_d and rr_d down the path (rendering.rs:89-98); (rho (1 - s))^90 ~ 1e-14
+            nxt = T * rho
+            lum = min(1.0, 0.2126 * nxt[0] + 0.7152 * nxt[1] + 0.0722 * nxt[2])
+            p = 1.0 if d < 4 else lum * 0.5 ** (d - 4) if d >= 50 else lum
+            rr.append(p)
+            T = np.minimum(nxt / p, 1e30)                       # (beyond depth 50 the carried throughput explodes; its luminance clamps at 1)
+        E = np.zeros(3)
+        for d in reversed(range(90)):
+            E = rho * le * (rr[d] * d_nee + d_bsdf) + rho * (1.0 - s) * E
+        want = E
+        assert want[0] < 0.9 * L[0] and np.all(want < L)        # Q1 costs the red channel (albedo 0.7: long paths) 12 %
+    mean, sem = _gpu_mean(gpu_ctx, pt, origin, target, integrator=0 if mis else 1, min_depth=min_depth, max_depth=50)
+    _check(mean, sem, want, case)
+    if mis and min_depth == 4:
+        assert abs(mean[0] - L[0]) > 20.0 * sem[0]
