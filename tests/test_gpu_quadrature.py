@@ -621,3 +621,26 @@ def test_integrating_sphere_every_bounce_in_closed_form(pt, gpu_ctx, case):
     _check(mean, sem, want, case)
     if mis and min_depth == 4:
         assert abs(mean[0] - L[0]) > 20.0 * sem[0]
+
+
+@pytest.mark.parametrize("case", ["mis, no roulette", "brdf only, roulette from depth 4"])
+def test_integrating_sphere_image_through_the_throughput_kernels(pt, gpu_ctx, case):
+    """The same closed form through the whole-frame path -- camera rays, the regenerating path kernel (a batch of 2^22 paths), the
+    film resolve -- instead of pt_ray_color's pixel lists: a camera inside the integrating sphere that looks away from the light
+    sees the wall in every pixel, so every pixel's expectation is L = rho Le s / (1 - rho (1 - s)).  256 x 256 x 64 spp; the mean
+    over the pixels against L at 4 standard errors (pixels are independent), and no pixel far from it."""
+    R, r = 2.0, 0.3
+    le, rho = np.array([20.0, 14.0, 9.0]), np.array([0.7, 0.5, 0.25])
+    s = (r / R) ** 2
+    gpu_ctx.upload(pt.make_objects([(SPH, [0, 0, 0, R], LAMBERT, list(rho)), (SPH, [0, 0, 0, r], EMISSIVE, list(le))]))
+    cam = pt.camera_look_at((0.6, 0.3, 0.2), (1.6, 0.7, 0.5), (0.0, 1.0, 0.0), 256, 256, 35.0)
+    mis = case.startswith("mis")
+    prm = pt.default_params(spp=64, integrator=0 if mis else 1, min_depth=50 if mis else 4, max_depth=50)
+    lin, _ = gpu_ctx.render(cam, prm)
+    st = gpu_ctx.stats()
+    assert st.samples == 256 * 256 * 64 and st.bounce_launches == 1
+    img = lin.cpu().numpy().astype(np.float64).reshape(-1, 3)
+    L = rho * le * s / (1.0 - rho * (1.0 - s))
+    mean, sem = img.mean(0), img.std(0, ddof=1) / np.sqrt(img.shape[0])
+    _check(mean, sem, L, case)
+    assert np.all(np.abs(img - L) < 60.0 * sem * np.sqrt(img.shape[0]))          # every pixel within its own spread of L
