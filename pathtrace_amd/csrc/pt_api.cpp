@@ -182,15 +182,15 @@ struct PtContext {
     // multi-batch renders: the continuation launches and the film resolve of batch k run on side_stream while the
     // level-0 launch of batch k + 1 runs on the caller's stream (their own queue and a second sample buffer)
     hipStream_t side_stream = nullptr;
-    // regenerating launches: two LANES (stream + sample buffer + launch counters each) taken in turn by consecutive sample
-    // batches -- of one render or of renders enqueued back to back --, so that the launch of batch k + 1 fills the device
-    // while the last waves of batch k run dry; the resolves stay in order on the caller's stream
+    // regenerating launches: kLanes LANES (streams of their own) taken in turn by consecutive sample batches -- of one render or
+    // of renders enqueued back to back --, so that the launches of batches k + 1 and k + 2 fill the device while the last waves
+    // of batch k run dry; the resolves stay in order on the caller's stream
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t lane_done[kLanes] = {}, lane_begun[kLanes] = {}, ev_pre = nullptr, ev_switch = nullptr;
     bool lane_used[kLanes] = {};
-    // ... and THREE buffer sets (sample buffer + launch counters) taken in turn: a resolve cannot run beside a resident
-    // regenerating launch (it gets no wave slots until that launch runs dry: measured), so the resolve of batch k only
-    // runs while batch k + 1 drains -- and batch k + 2's launch, which starts at that moment too, must not wait for it
+    // ... and kSets buffer sets (sample buffer + launch counters) taken in turn: a resolve gets few wave slots beside resident
+    // regenerating launches (146 us of work take ~0.9 ms: measured), so the launch of batch k + kSets is the first to wait for
+    // the resolve of batch k
     hipEvent_t set_free[kSets] = {};
     bool set_used[kSets] = {};
     uint32_t set_next = 0;
@@ -766,11 +766,11 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // only the 23-VGPR resolve kernel beside it, which would fit: 8 590 against 10 780.)
     const uint32_t regen_export = split ? 1u : c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;   // the split form has no hand-over
     const bool overlap = n_batches > 1 && !regen;
-    // Regenerating launches whose waves run dry themselves take the two lanes in turn (PtContext): the launch of the next
-    // batch -- the next render's, when renders are enqueued back to back -- starts on the other lane's stream as soon as that
-    // lane's stream is free, i.e. while this batch's last waves are still running dry (the ~0.4 ms in which a launch holds the
-    // device half empty: one rank's share of C2 at 8 ranks 1.04 -> 0.95 ms per render, profiles/r04/).  Resolves stay on the
-    // caller's stream, in order.  Not while that stream is being captured into a graph: the capture takes the in-order form.
+    // Regenerating launches whose waves run dry themselves take the lanes in turn (PtContext): the launch of the next batch --
+    // the next render's, when renders are enqueued back to back -- goes to the next lane's stream and starts as soon as that
+    // stream and its buffer set are free, i.e. while earlier launches are still running (the ~0.4 ms in which a launch alone holds
+    // the device half empty while it runs dry: one rank's share of C2 at 8 ranks 1.03 -> 0.76 ms per render, profiles/r04/).
+    // Resolves stay on the caller's stream, in order.  Not while that stream is being captured into a graph: the capture takes the in-order form.
     // Nor with profile = 1: launches that overlap cannot be timed one by one (an event pair around a launch would span its wait
     // for wave slots too), so a profiled render keeps them in order.
     bool lanes = false;
@@ -927,7 +927,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
                 ls = c->lane_stream[lane];
                 if (c->set_used[par]) HIP_TRY(hipStreamWaitEvent(ls, c->set_free[par], 0));      // (the resolve of kSets batches ago)
                 if (lanes_wait_pre && !lane_waited_pre[lane]) { HIP_TRY(hipStreamWaitEvent(ls, c->ev_pre, 0)); lane_waited_pre[lane] = true; }
-                // ... and not before the other lane's launch has been handed to the device: two launches that become
+                // ... and not before the previous lane's launch has been handed to the device: two launches that become
                 // ready at the same moment would share the device from the start and run dry together
                 const int prev_lane = (lane + kLanes - 1) % kLanes;       // the lane of the launch before this one
                 if (c->lane_used[prev_lane]) HIP_TRY(hipStreamWaitEvent(ls, c->lane_begun[prev_lane], 0));
