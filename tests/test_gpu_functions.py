@@ -369,26 +369,27 @@ def test_pipelined_renders_with_changing_launch_sizes_keep_their_exchange_memory
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_sequences_of_pipelined_renders_equal_isolated_renders(pt, seed):
-    """The scheduling machinery of round 4 under a random load: TWO contexts on the device (C2 -> k_paths_regen, the reference
-    scene -> k_paths_regen_split with its per-lane exchange memory), 28 renders posted back to back without a host wait, in random
-    order over the two contexts -- whole images and row-band tiles, one to four sample batches per render (max_paths_in_flight),
+    """The scheduling machinery of round 4 under a random load: THREE contexts on the device (C2 -> k_paths_regen, the reference
+    scene -> k_paths_regen_split with its per-lane exchange memory, an OrenNayar Cornell box -> the kernel without the Mirror
+    code), both integrators, 28 renders posted back to back without a host wait, in random order over the contexts -- whole images and row-band tiles, one to four sample batches per render (max_paths_in_flight),
     small jobs that take the queue form in between, exact and default arithmetic, a tuned grid now and then.  Lanes, buffer sets,
     spare workgroups, the counters the resolves clear: whatever they do, every film must equal the one the same job gives when it
     runs alone and in order, bit for bit, and the statistics must add up."""
     import torch
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda", 0)
-    ctxs = [pt.Context(0), pt.Context(0)]
+    ctxs = [pt.Context(0), pt.Context(0), pt.Context(0)]
     try:
         ctxs[0].upload(pt.builtin_scene(2))
         ctxs[1].upload(pt.builtin_scene(1))
+        ctxs[2].upload(_oren_nayar_cornell(pt))
         jobs = []
         for _ in range(28):
-            which = int(rng.integers(0, 2))
+            which = int(rng.integers(0, 3))
             W, H = [(256, 256), (320, 200), (512, 128), (64, 48)][int(rng.integers(0, 4))]
             spp = int(rng.choice([4, 8, 12]))
             bands = int(rng.choice([1, 1, 2, 3]))
-            kw = dict(spp=spp, exact_math=int(rng.integers(0, 2)), spp_offset=int(rng.integers(0, 1000)))
+            kw = dict(spp=spp, exact_math=int(rng.integers(0, 2)), spp_offset=int(rng.integers(0, 1000)), integrator=int(rng.random() < 0.25))
             if bands > 1:
                 kw.update(band_rows=int(rng.choice([8, 16, 50])), band_index=int(rng.integers(0, bands)), band_count=bands)
             if rng.random() < 0.4:
@@ -402,7 +403,7 @@ def test_random_sequences_of_pipelined_renders_equal_isolated_renders(pt, seed):
             lin, rgba = ctxs[which].render(cam, pt.default_params(**kw))
             refs.append((lin.clone(), rgba.clone(), ctxs[which].stats().vertices))
         # ... and all of them posted back to back
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        streams = [torch.cuda.Stream(dev) for _ in ctxs]
         for c, st in zip(ctxs, streams):
             c.set_stream(st.cuda_stream)
         outs = [(torch.zeros_like(r[0]), torch.zeros_like(r[1])) for r in refs]
@@ -418,7 +419,7 @@ def test_random_sequences_of_pipelined_renders_equal_isolated_renders(pt, seed):
                for k, ((lin_d, rgba_d), (lin, rgba, _)) in enumerate(zip(outs, refs))
                if not (torch_equal(lin_d.view(torch.int32), lin.view(torch.int32)) and torch_equal(rgba_d, rgba))]
         assert not bad, bad
-        for which in (0, 1):
+        for which in range(len(ctxs)):
             assert ctxs[which].stats().vertices == sum(r[2] for r, j in zip(refs, jobs) if j[0] == which)
     finally:
         for c in ctxs:

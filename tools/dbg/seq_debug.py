@@ -6,15 +6,22 @@ import pathtrace_amd as pt
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda", 0)
-ctxs = [pt.Context(0), pt.Context(0)]
-ctxs[0].upload(pt.builtin_scene(2)); ctxs[1].upload(pt.builtin_scene(1))
+def oren_nayar_cornell():
+    objs = list(pt.builtin_scene(2))
+    for k, o in enumerate(objs):
+        if o.mat_tag == 0:
+            o.mat_tag = 3
+            o.mat[3] = [0.0, 0.3, 0.6, 1.0][k % 4]
+    return (pt._lib.PtObject * len(objs))(*objs)
+ctxs = [pt.Context(0), pt.Context(0), pt.Context(0)]
+ctxs[0].upload(pt.builtin_scene(2)); ctxs[1].upload(pt.builtin_scene(1)); ctxs[2].upload(oren_nayar_cornell())
 jobs = []
 for _ in range(28):
-    which = int(rng.integers(0, 2))
+    which = int(rng.integers(0, 3))
     W, H = [(256, 256), (320, 200), (512, 128), (64, 48)][int(rng.integers(0, 4))]
     spp = int(rng.choice([4, 8, 12]))
     bands = int(rng.choice([1, 1, 2, 3]))
-    kw = dict(spp=spp, exact_math=int(rng.integers(0, 2)), spp_offset=int(rng.integers(0, 1000)))
+    kw = dict(spp=spp, exact_math=int(rng.integers(0, 2)), spp_offset=int(rng.integers(0, 1000)), integrator=int(rng.random() < 0.25))
     if bands > 1:
         kw.update(band_rows=int(rng.choice([8, 16, 50])), band_index=int(rng.integers(0, bands)), band_count=bands)
     if rng.random() < 0.4:
@@ -26,7 +33,7 @@ for which, (W, H), kw, tune in jobs:
     ctxs[which].set_tuning(in_order=1, regen_workgroups=tune)
     lin, rgba = ctxs[which].render(pt.camera_new(width=W, height=H), pt.default_params(**kw))
     refs.append((lin.clone(), rgba.clone(), ctxs[which].stats().vertices))
-streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+streams = [torch.cuda.Stream(dev) for _ in ctxs]
 for c, st in zip(ctxs, streams): c.set_stream(st.cuda_stream)
 outs = [(torch.zeros_like(r[0]), torch.zeros_like(r[1])) for r in refs]
 for c in ctxs: c.sync(); c.stats()
