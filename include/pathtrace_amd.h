@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 typedef enum {
     PT_OK = 0,
@@ -147,7 +147,9 @@ typedef struct {
  * pt_render_device calls behind one synchronisation gets their sums; total_ms then runs from the first one's start to the
  * last one's end. */
 typedef struct {
-    uint64_t samples;          /* camera samples traced = tile pixels * spp    */
+    uint64_t samples;          /* camera samples FINISHED, counted on the device where a path's radiance is written to the
+                                  sample buffer.  pt_sync / pt_get_stats fail with PT_ERR_HIP when it differs from
+                                  samples_expected: a render lost or repeated work and its film is not to be trusted  */
     uint64_t vertices;         /* path vertices processed (iterations of the
                                   per-vertex loop)                 */
     uint64_t shadow_rays;      /* NEE visibility scans                         */
@@ -165,6 +167,8 @@ typedef struct {
     double   primary_kernel_ms;/* sum of their HIP-event durations (profile=1)                    */
     uint32_t primary_launches;
     uint32_t reserved2;
+    uint64_t samples_expected; /* tile pixels * spp of the renders enqueued (host arithmetic); renders captured into a graph
+                                  count by replay: `samples` may then exceed this by multiples of the captured renders' size */
 } PtStats;
 
 /* ---- helpers ------------------------------------------------------------ */
@@ -342,6 +346,34 @@ int pt_debug_multi_create_shared(int device, uint32_t n, PtMulti** out);
  * fail, and the call then returns the status the drain reported.                                                     */
 int pt_debug_feeder_selftest(uint32_t n_workers, uint32_t n_frames, uint32_t spin, int32_t fail_at,
                              uint64_t* order_out, uint32_t* n_out);
+
+/* The launch scheduler of a context, host only (no GPU needed).  A render is planned by a PURE function (csrc/pt_sched.h):
+ * (scheduling state of the context, job) -> the list of stream operations the render enqueues -- path-kernel launches and film
+ * resolves with their stream, buffer set, lane, exchange region and counters, the event records / waits that order them, the
+ * fills of counters and statistics.  pt_render_device* executes exactly such a list.  These entries run the same function on a
+ * scheduling state of their own, so that a test can drive random sequences of jobs through it and check the invariants of
+ * DESIGN.md 3 with a happens-before simulator (tests/test_sched_cpu.py).  Field meanings: csrc/pt_sched.h (Job, Op).         */
+typedef struct {
+    uint32_t n_batches, regen, split, hand_off, regen_export, profile, in_order, capturing;
+    uint32_t grid, regen_grid, cont_grid, regen_capacity, fixed_grid, counter_words;
+    uint64_t xchg_need;
+} PtSchedJob;
+typedef struct {
+    uint32_t kind, stream, event, pool, set, lane, level, own_queue, ovf_par, batch, grid, seq, core, flags, zero_words, reserved;
+    uint64_t xchg_off, xchg_len;
+} PtSchedOp;
+typedef struct PtSched PtSched;
+int pt_debug_sched_create(PtSched** out);
+void pt_debug_sched_destroy(PtSched* s);
+/* Plans one render and advances the state.  faults: bit 0 / bit 1 switch round 4's two scheduling bugs back on (pt_sched.h:
+ * Faults; for the test that shows they are caught).  fail_after < the plan's length: the operation of that index fails as a
+ * HIP call would -- only the operations before it are returned, followed by the host synchronisation of the recovery, and the
+ * state is what render_impl's recovery leaves.  *lanes = 1 if the render took the lanes.                                     */
+int pt_debug_sched_render(PtSched* s, const PtSchedJob* job, uint32_t faults, uint32_t fail_after, PtSchedOp* ops, uint32_t cap,
+                          uint32_t* n_ops, uint32_t* lanes);
+int pt_debug_sched_sync(PtSched* s, uint32_t collect);        /* pt_sync: everything enqueued is complete (collect: statistics read and cleared) */
+/* Test hook: the n-th stream operation (0-based) of the NEXT render on this context fails as if its HIP call had (n < 0: none). */
+int pt_debug_fail_after(PtContext* ctx, int64_t n);
 
 /* World::render_pixel (src/world.rs:293-333) -- the seam the reference's rayon loop calls at
  * src/main.rs:55 -- for an arbitrary list of n pixels: xy = n * (x, y), y = film row (top-down, the y

@@ -79,7 +79,18 @@ class PtStats(C.Structure):
         ("primary_kernel_ms", C.c_double),
         ("primary_launches", C.c_uint32),
         ("reserved2", C.c_uint32),
+        ("samples_expected", C.c_uint64),
     ]
+
+
+class PtSchedJob(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_batches", "regen", "split", "hand_off", "regen_export", "profile", "in_order", "capturing",
+                                          "grid", "regen_grid", "cont_grid", "regen_capacity", "fixed_grid", "counter_words")] + [("xchg_need", C.c_uint64)]
+
+
+class PtSchedOp(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("kind", "stream", "event", "pool", "set", "lane", "level", "own_queue", "ovf_par", "batch", "grid",
+                                          "seq", "core", "flags", "zero_words", "reserved")] + [("xchg_off", C.c_uint64), ("xchg_len", C.c_uint64)]
 
 
 class PtMultiInfo(C.Structure):
@@ -150,6 +161,11 @@ SYMBOLS = {
     "pt_multi_info": (C.c_int, [C.c_void_p, _P(PtMultiInfo)]),
     "pt_debug_multi_create_shared": (C.c_int, [C.c_int, C.c_uint32, _P(C.c_void_p)]),
     "pt_debug_feeder_selftest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _P(C.c_uint64), _P(C.c_uint32)]),
+    "pt_debug_sched_create": (C.c_int, [_P(C.c_void_p)]),
+    "pt_debug_sched_destroy": (None, [C.c_void_p]),
+    "pt_debug_sched_render": (C.c_int, [C.c_void_p, _P(PtSchedJob), C.c_uint32, C.c_uint32, _P(PtSchedOp), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
+    "pt_debug_sched_sync": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pt_debug_fail_after": (C.c_int, [C.c_void_p, C.c_int64]),
     "pt_multi_scene_upload": (C.c_int, [C.c_void_p, _P(PtObject), C.c_uint32]),
     "pt_multi_set_tuning": (C.c_int, [C.c_void_p, _P(PtTuning)]),
     "pt_multi_render_device": (C.c_int, [C.c_void_p, _P(PtCamera), _P(PtRenderParams), C.c_void_p, C.c_void_p]),

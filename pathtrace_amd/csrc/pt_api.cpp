@@ -20,6 +20,7 @@
 #include "../../include/pathtrace_amd.h"
 #include "pt_bvh.h"
 #include "pt_kernels.h"
+#include "pt_sched.h"
 
 static thread_local std::string g_err;
 namespace {
@@ -75,31 +76,9 @@ constexpr uint32_t kContGrid = 1024;
 #ifndef PT_REGEN_EXPORT
 #define PT_REGEN_EXPORT 1
 #endif
-#ifndef PT_LANE_OVERLAP
-#define PT_LANE_OVERLAP 1
-#endif
-constexpr bool kLaneOverlap = PT_LANE_OVERLAP != 0;
-#ifndef PT_LANES
-#define PT_LANES 3
-#endif
-#ifndef PT_LANE_GRID24
-#define PT_LANE_GRID24 11
-#endif
-constexpr uint32_t kLaneGrid24 = PT_LANE_GRID24;      // core of a launch that overlaps its neighbours, in 24ths of what the device holds (k_paths_regen)
-#ifndef PT_LANE_GRID24_SPLIT
-#define PT_LANE_GRID24_SPLIT 12
-#endif
-constexpr uint32_t kLaneGrid24Split = PT_LANE_GRID24_SPLIT;   // ... k_paths_regen_split (5 workgroups per CU): C1 7.26 ms per step at 11, 7.13 at 12, 7.18 at 13
-constexpr int kLanes = PT_LANES;        // streams the regenerating launches of consecutive batches take in turn (2 or 3)
-// Buffer sets (sample buffer + launch counters) the lanes' launches rotate through: launch k waits for the resolve of launch
-// k - kSets.  With three, launch k + 3 waits for resolve k, which gets few wave slots beside the resident launches (146 us of work
-// take ~0.9 ms).  A fourth set, so that it need not, was measured and LOSES: the resolve then competes with one more pending launch
-// (C2 5.67 -> 6.1 ms per step, C1 7.15 -> 7.3; profiles/r04/ab_four_buffer_sets.txt).
-#ifndef PT_SETS
-#define PT_SETS 3
-#endif
-constexpr int kSets = PT_SETS;          // 3 or 4
-static_assert(kSets >= 3 && kSets <= 4, "PT_SETS: 3 or 4");
+// lanes, buffer sets and the core size of overlapping launches: pt_sched.h (the scheduler's constants)
+using ptsched::kLanes;
+using ptsched::kSets;
 constexpr uint32_t kStatsWords = 32;            // 16 x u64 at the front of the counter buffer: 8 render statistics, 8 words for measurement builds (PT_DRAIN_TIMING)
 constexpr uint32_t kCountStride = (1 + ptk::kRegenCounters) * ptk::kRegenCounterStride;   // uint32 per batch parity: leftover count + chunk counters
 #ifndef PT_SPLIT_BY_DEFAULT
@@ -128,7 +107,6 @@ constexpr uint32_t kExportMinPaths = 1u << PT_EXPORT_MIN_LOG2;
 #endif
 constexpr uint32_t kRegenMinPaths = 1u << PT_REGEN_MIN_LOG2;
 constexpr uint32_t kWavesPerBlock = ptk::kBlock / 64;
-constexpr uint32_t kMaxProfiledLaunches = 1u << 14;      // bound of the HIP-event pool (profile = 1) between two collections of the statistics
 // PT_ACCEL_AUTO: the BVH when the scene is larger than one LDS blob and spheres + 2.5 x triangles > 512 (C4-like
 // scenes: the tiled scan costs ~0.11 ms per sphere and 67 M samples -- a Moeller-Trumbore test 2.5x that --, the BVH
 // ~70 ms flat -> break-even near 600 sphere tests)
@@ -173,8 +151,7 @@ struct PtContext {
     bool split_ok = false;            // a minority of the objects is Mirror: the regenerating form that batches their vertices pays
     uint32_t scan_counts[3] = {0, 0, 0};   // entries of the scan array by kind: spheres, single triangles, triangle pairs (pt_debug_scan_layout)
     // wavefront state
-    DevBuf<float4> xchg;              // k_paths_regen_split: exchange stacks of every wave, one region per lane
-    size_t xchg_stride = 0;           // float4 per lane region (grows only while every lane is idle)
+    DevBuf<float4> xchg;              // k_paths_regen_split: exchange stacks of every wave, one region per lane (stride: sched.xchg_stride)
     DevBuf<float4> queue[4];
     DevBuf<float4> bvh_aux, bvh_sray[2];   // accel = 1: per-slot scratch of the staged passes (k_paths_bvh)
     DevBuf<float4> ovf[2][2][4];      // overflow queues of the tail hand-off: per batch parity: leftover count, chunk counters (kCountStride)[plane]
@@ -187,15 +164,17 @@ struct PtContext {
     // of batch k run dry; the resolves stay in order on the caller's stream
     hipStream_t lane_stream[kLanes] = {};
     hipEvent_t lane_done[kLanes] = {}, lane_begun[kLanes] = {}, ev_pre = nullptr, ev_switch = nullptr;
-    bool lane_used[kLanes] = {};
     // ... and kSets buffer sets (sample buffer + launch counters) taken in turn: a resolve gets few wave slots beside resident
     // regenerating launches (146 us of work take ~0.9 ms: measured), so the launch of batch k + kSets is the first to wait for
     // the resolve of batch k
     hipEvent_t set_free[kSets] = {};
-    bool set_used[kSets] = {};
-    uint32_t set_next = 0;
     DevBuf<ptk::Rgb> lsamp3, lsamp4;
-    uint32_t lane_next = 0;
+    // Which lane / buffer set comes next, which events have been recorded, which device-side words are known to be zero: the
+    // scheduling state.  render_impl plans on a copy (ptsched::plan, pure) and commits it after the last operation was enqueued.
+    ptsched::State sched;
+    uint64_t expected_samples = 0;    // tile pixels x spp of the renders enqueued since the statistics were last collected (pt_sync compares)
+    uint64_t capture_gcd = 0;         // gcd of the sample counts of the renders captured into graphs (replays add multiples of them)
+    int64_t debug_fail_at = -1;       // pt_debug_fail_after: the stream operation of the next render that fails (test hook)
     DevBuf<float4> cqueue[4];
     DevBuf<float4> caux, csray[2];    // ... and, for accel = 1, its own staged-pass scratch
     DevBuf<ptk::Rgb> lsamp2;
@@ -209,20 +188,11 @@ struct PtContext {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     PtStats stats{};
-    bool stats_pending = false;
-    // the device-side counters: the render statistics are zero (cleared when they were last collected) / the launch
-    // counters of batch parity 0, 1 are zero (the resolve of the batch that used them last cleared them) -- a render
-    // then needs no memset in the stream
-    bool stats_clean = false;
-    bool counters_clean[kSets] = {};
     uint32_t regen_occ[2][2][2] = {};          // cached occupancy query [exact_math][integrator][split] of this scene (0: not asked yet)
-    uint32_t profiled_batches = 0;             // event slots (launch begin / end pairs) in use since the statistics were last collected
     std::vector<uint32_t> primary_events;      // slots of the level-0 launches
     PtTuning tuning{};                         // pt_context_set_tuning; 0 = library default
     uint32_t* h_posted = nullptr;              // host memory the device reads: number of the last lanes launch enqueued (BounceArgs.posted)
     uint32_t* d_posted = nullptr;              // ... its device address
-    uint32_t lane_seq = 0;
-    bool stream_work_since_lanes = false;      // a render without lanes has been enqueued since the last one with (render_impl)
     bool bvh_failed = false;                   // the BVH builder refused this scene (depth): PT_ACCEL_AUTO stays with the scan
     // pixel-list entries (pt_render_pixels, pt_ray_color)
     DevBuf<uint2> pixel_list;
@@ -576,8 +546,8 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     if ((rc = c->runs.ensure(runs.size() + 1))) return rc;
     if ((rc = c->lights.ensure(lights.size() + 1))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));   // the previous scene may still be in use
-    c->stats_pending = false;                    // statistics of renders of the previous scene do not carry over
-    c->stats_clean = false;                      // (their device-side counters are cleared by the next render)
+    ptsched::on_scene(c->sched);                 // statistics of renders of the previous scene do not carry over
+    c->expected_samples = 0;
     std::memset(c->regen_occ, 0, sizeof c->regen_occ);
     if (!scan.empty()) HIP_TRY(hipMemcpy(c->scan.p, scan.data(), scan.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->shape.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -651,8 +621,42 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
 
 namespace {
 
+// ---- the launch scheduler: plan (pt_sched.h, pure) -> execute (here) -> commit
+hipStream_t sched_stream(const PtContext* c, hipStream_t caller, uint32_t id) {
+    return id == ptsched::kStreamCaller ? caller : id == ptsched::kStreamSide ? c->side_stream : c->lane_stream[id - ptsched::kStreamLane0];
+}
+hipEvent_t sched_event(const PtContext* c, const ptsched::Op& o) {
+    using namespace ptsched;
+    const uint32_t e = o.event;
+    if (e == kEvBegin) return c->ev_begin;
+    if (e == kEvEnd) return c->ev_end;
+    if (e == kEvPre) return c->ev_pre;
+    if (e >= kEvL0 && e < kEvResolved) return c->ev_l0[e - kEvL0];
+    if (e >= kEvResolved && e < kEvLaneDone) return c->ev_resolved[e - kEvResolved];
+    if (e >= kEvLaneDone && e < kEvLaneBegun) return c->lane_done[e - kEvLaneDone];
+    if (e >= kEvLaneBegun && e < kEvSetFree) return c->lane_begun[e - kEvLaneBegun];
+    if (e >= kEvSetFree && e < kEvPool) return c->set_free[e - kEvSetFree];
+    return c->ev_pool[o.pool];
+}
+DevBuf<ptk::Rgb>& sample_buffer(PtContext* c, uint32_t set) { return set == 3 ? c->lsamp4 : set == 2 ? c->lsamp3 : set ? c->lsamp2 : c->lsamp; }
+
+// An operation of a render could not be enqueued: what was enqueued before it runs to its end (or fails with the device), then
+// the scheduling state starts over with nothing known to be clean (ptsched::on_failure).  The render's outputs are undefined;
+// the statistics of the renders since the last collection are dropped with it.
+void sched_recover(PtContext* c, hipStream_t st, const ptsched::State& planned) {
+    for (int k = 0; k < kLanes; ++k) (void)hipStreamSynchronize(c->lane_stream[k]);
+    (void)hipStreamSynchronize(c->side_stream);
+    (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    ptsched::on_failure(c->sched, planned);
+    c->expected_samples = 0;
+}
+
 // The render driver behind every rendering entry: everything src/main.rs:43-60 does for the tile (or, with `list`,
 // for a pixel list / a set of given rays).  Enqueues on the context's streams and returns; no host synchronisation.
+// Three steps: PREPARE (validate, size, allocate every buffer the render will touch -- nothing is enqueued yet, so an
+// error here leaves the context as it was), PLAN (ptsched::plan on a copy of the scheduling state: pure), EXECUTE (the
+// plan's stream operations in order) and COMMIT of the copy.  A failure during EXECUTE: sched_recover.
 int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, const FilmState& fs, const ListRender* list,
                 float* d_linear, uint8_t* d_rgba, void* d_packed = nullptr) {
     if (!c || !cam || !prm) return fail(PT_ERR_INVALID_ARG, "render: null argument");
@@ -666,6 +670,9 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const uint32_t band_count = prm->band_count ? prm->band_count : 1;
     if (prm->band_index >= band_count) return fail(PT_ERR_INVALID_ARG, "band_index %u >= band_count %u", prm->band_index, band_count);
     if (list && band_count != 1) return fail(PT_ERR_INVALID_ARG, "pixel-list renders take the whole image (band_count = 1)");
+    // the resolve stores a pixel's RGBA8 as one 32-bit word (a byte-offset pointer would fault on the device)
+    if (d_rgba && (uintptr_t)d_rgba % 4u) return fail(PT_ERR_INVALID_ARG, "render: the RGBA8 output buffer must be 4-byte aligned");
+    if (d_linear && (uintptr_t)d_linear % 4u) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer must be 4-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     PtRenderParams resolved = *prm;      // PT_ACCEL_AUTO -> what actually runs
@@ -684,13 +691,15 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     // Statistics belong to the renders enqueued since they were last collected (pt_sync / pt_get_stats): a caller that
     // pipelines several renders behind one synchronisation gets their sums (vertices, launches, kernel times), total_ms from
     // the first one's start to the last one's end.  One render per synchronisation: the statistics of that render, as ever.
-    const bool accumulate = c->stats_pending;
-    if (!accumulate) {
+    auto begin_period = [c]() {        // the first render since the last collection
         std::memset(&c->stats, 0, sizeof c->stats);
-        c->profiled_batches = 0;
         c->primary_events.clear();
+        c->expected_samples = 0;
+    };
+    if (np64 == 0) {                   // empty tile: nothing to render
+        if (!c->sched.stats_pending) begin_period();
+        return PT_OK;
     }
-    if (np64 == 0) return PT_OK;   // empty tile: nothing to render
     if (!d_linear && !d_packed) return fail(PT_ERR_INVALID_ARG, "render: the linear output buffer is null");
     if (!list && (cam->width > 65535u || tile_rows > 65535u))   // (tile row, x) share one word of the path state
         return fail(PT_ERR_UNSUPPORTED, "tile %ux%llu: width and tile rows must be < 65536", cam->width, (unsigned long long)tile_rows);
@@ -735,8 +744,6 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const bool hand_off = !inject && n_paths_max > (regen_scene ? kRegenMinPaths : kExportMinPaths);
     // Such a batch over a scene in LDS takes the regenerating level-0 kernel: paths live in registers, a lane whose
     // path ends takes the next one of the batch; grid = the waves the device holds at once (k_paths_regen).
-    // (Scenes with GGX / OrenNayar surfaces keep the queue form unless asked: paths of every depth and material share a
-    // wave there, and the divergence costs what the form saves -- C1 12.40 vs 12.21 ms.)
     const bool regen = regen_scene && hand_off;
     // its grid = the workgroups the device holds at once: the kernel's occupancy with THIS scene's LDS blob (a 128-object
     // scene leaves room for fewer workgroups per CU than the compile-time figure)
@@ -751,7 +758,7 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
         if (occ != 0u) regen_per_cu = std::min(regen_per_cu, occ);
     }
     const uint32_t regen_capacity = c->n_cus * regen_per_cu;          // workgroups the device holds at once
-    uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups : regen_capacity);
+    const uint32_t regen_grid = std::min(65536u, prm->workgroups ? prm->workgroups : c->tuning.regen_workgroups ? c->tuning.regen_workgroups : regen_capacity);
     const uint32_t cont_grid = c->tuning.cont_workgroups ? std::min(65536u, c->tuning.cont_workgroups) : kContGrid;
     const uint32_t nw_cont = cont_grid * kWavesPerBlock;
     // leftovers per wave of the level-0 launch: < export_small from a wave-private segment, < 256 per workgroup
@@ -760,38 +767,27 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     const uint32_t seg_cap_cont = (uint32_t)((((ovf_slots + 63) / 64 + nw_cont - 1) / nw_cont) * 64u);
     const size_t q_slots_cont = hand_off ? (size_t)nw_cont * seg_cap_cont : 0;
     const size_t q_slots = regen ? std::max<size_t>(q_slots_cont, 64) : std::max((size_t)nw * seg_cap, q_slots_cont);
-    // Multi-batch renders overlap the tail of batch k (continuation launch, resolve) with the body of batch k + 1
-    // (Not beside a regenerating level-0 launch: its waves hold every wave slot of the device for the whole launch, and
-    // a tail that has to squeeze in beside them stretches both -- C3 8 900 Msamples/s overlapped, 10 220 in order; with
-    // only the 23-VGPR resolve kernel beside it, which would fit: 8 590 against 10 780.)
     const uint32_t regen_export = split ? 1u : c->tuning.export_below ? std::min(export_small, 64u) : kRegenExportBelow;   // the split form has no hand-over
-    const bool overlap = n_batches > 1 && !regen;
-    // Regenerating launches whose waves run dry themselves take the lanes in turn (PtContext): the launch of the next batch --
-    // the next render's, when renders are enqueued back to back -- goes to the next lane's stream and starts as soon as that
-    // stream and its buffer set are free, i.e. while earlier launches are still running (the ~0.4 ms in which a launch alone holds
-    // the device half empty while it runs dry: one rank's share of C2 at 8 ranks 1.03 -> 0.76 ms per render, profiles/r04/).
-    // Resolves stay on the caller's stream, in order.  Not while that stream is being captured into a graph: the capture takes the in-order form.
-    // Nor with profile = 1: launches that overlap cannot be timed one by one (an event pair around a launch would span its wait
-    // for wave slots too), so a profiled render keeps them in order.
-    bool lanes = false;
-    if (kLaneOverlap && regen && regen_export <= 1u && prm->profile == 0u && c->tuning.in_order == 0u) {
+    // (sized by the grid the launch really takes: never more workgroups than the largest batch has chunks for)
+    const uint32_t regen_launch_grid = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
+
+    // ---- the job as the scheduler sees it (pt_sched.h)
+    ptsched::Job job;
+    job.n_batches = n_batches;
+    job.regen = regen; job.split = regen && split; job.hand_off = hand_off; job.regen_export = regen_export;
+    job.profile = prm->profile != 0; job.in_order = c->tuning.in_order != 0;
+    {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        lanes = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        job.capturing = !(hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone);
         (void)hipGetLastError();
     }
-    // With lanes the first kLaneGrid24 / 24 of a launch's workgroups -- LESS than half of what the device holds -- are its core, the
-    // others spare (BounceArgs.posted): in a sequence of launches two cores are resident side by side, a phase apart, and the third
-    // fills the slots the first frees while it runs dry -- the device never waits for one launch's last waves -- while the spare
-    // workgroups end as soon as they get a slot and see that two launches are enqueued behind theirs.  Those of the last two
-    // launches of a sequence, and of a launch on its own (a host that synchronises after every render), see no such successors
-    // and take the rest of the device.  Measured (tools/r04/share_grid.py, C2, ms per render, 3 lanes): the whole image 6.01 with
-    // full-size launches, 5.69 with cores of 704 of 1536 workgroups (5.82 at exactly half: no room for the third); one rank's
-    // share at 8 ranks 0.95 -> 0.78; cores of 9 .. 11 / 24 are within noise of one another on C2 (5.65 - 5.68 ms per step), 12 and
-    // 13 cost 3 - 4 % (profiles/r04/ab_lane_core_size.txt).  A launch that runs in order takes the whole device as before.
-    uint32_t regen_core = 0;                      // 0: no spare workgroups
-    if (lanes && !prm->workgroups && !c->tuning.regen_workgroups) regen_core = std::max(1u, regen_capacity * (split ? kLaneGrid24Split : kLaneGrid24) / 24u);
-    const bool two_sets = overlap || lanes;      // both parities of sample buffer / launch counters / hand-over queue in use
+    job.grid = grid; job.regen_grid = regen_launch_grid; job.cont_grid = cont_grid;
+    job.regen_capacity = regen_capacity;
+    job.fixed_grid = prm->workgroups != 0 || c->tuning.regen_workgroups != 0;
+    job.counter_words = kCountStride;
+    job.xchg_need = job.split ? (size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024 : 0;   // + slack: a violated stack invariant (reported) stays inside the buffer
 
+    // ---- PREPARE: every buffer the render will touch, before anything is enqueued
     int rc;
     if (prm->accel && (rc = ensure_bvh(c))) return rc;
     for (int k = 0; k < 4; ++k)
@@ -799,25 +795,25 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (prm->accel && ((rc = c->bvh_aux.ensure(q_slots)) || (rc = c->bvh_sray[0].ensure(q_slots)) ||
                        (rc = c->bvh_sray[1].ensure(q_slots))))
         return rc;
-    // (sized by the grid the launch really takes: never more workgroups than the largest batch has chunks for)
-    const uint32_t regen_launch_grid = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
-    // One region per lane (a launch may be in flight on each).  The lane stride is a property of the CONTEXT, not of this render:
-    // launches of earlier renders may still be using their regions, and the grid -- hence the memory a launch needs -- differs from
-    // render to render (whole device / a share of it, tuning).  It only ever grows, and only with every lane idle.
-    if (regen && split) {
-        const size_t need = (size_t)regen_launch_grid * kWavesPerBlock * ptk::kRegenSplitF4PerWave + 1024;   // + slack: a violated stack invariant (reported) stays inside the buffer
-        if (need > c->xchg_stride) {
-            for (int k = 0; k < kLanes; ++k) HIP_TRY(hipStreamSynchronize(c->lane_stream[k]));
-            HIP_TRY(hipStreamSynchronize(st));
-            c->xchg_stride = need;
+    {
+        // The buffer sets the render rotates through (with lanes: up to three sample buffers of 12 B per path in flight -- 3 x 3.2 GB
+        // for the reference's 400 x 400 x 3000 job at the default cap).  All of them now: an allocation in the middle of the batch
+        // loop would drain the pipeline the lanes keep full, and fail with half of the render enqueued.  If the device cannot hold
+        // them, the render falls back to ONE set and launches in order -- slower, same film -- instead of failing.
+        uint32_t sets[4], n_sets = 0;
+        ptsched::sets_of(c->sched, job, sets, &n_sets);
+        for (uint32_t k = 0; k < n_sets; ++k) {
+            rc = sample_buffer(c, sets[k]).ensure(n_paths_max);
+            if (rc == PT_ERR_OOM && ptsched::takes_lanes(job)) {
+                job.in_order = 1;
+                ptsched::sets_of(c->sched, job, sets, &n_sets);
+                k = (uint32_t)-1;                       // start over with the one set of the in-order form
+                continue;
+            }
+            if (rc) return rc;
         }
-        if ((rc = c->xchg.ensure(c->xchg_stride * kLanes))) return rc;
     }
-    const size_t xchg_lane = c->xchg_stride;
-    if ((rc = c->lsamp.ensure(n_paths_max))) return rc;
-    if (overlap && (rc = c->lsamp2.ensure(n_paths_max))) return rc;
-    // (lanes: the second and third sample buffer are allocated when a batch first takes them -- a host that synchronises
-    // after every single-batch render only ever uses the first set, pt_sync restarts the rotation)
+    const bool overlap = n_batches > 1 && !regen;
     if (overlap && hand_off)
         for (int k = 0; k < 4; ++k)
             if ((rc = c->cqueue[k].ensure(q_slots_cont))) return rc;
@@ -860,89 +856,62 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     a.bvh_refill = c->tuning.bvh_refill ? std::min(64u, c->tuning.bvh_refill) : ptk::kRefillBelow;
     a.bvh_leaf = c->tuning.bvh_leaf ? c->tuning.bvh_leaf : ptk::kLeafBatch;
 
-    // (a caller that pipelines profiled renders without ever collecting the statistics stops adding event pairs at kMaxProfiledLaunches:
-    // the launch times then cover the first that many launches)
-    const bool profile = prm->profile != 0 && c->profiled_batches + 2u * n_batches <= kMaxProfiledLaunches;
-    // The device-side words are normally zero already: the statistics were cleared when they were last collected
-    // (pt_sync), the launch counters by the resolve of the batch that used them last (ResolveArgs.zero_words).  Only a
-    // fresh or re-allocated buffer, a new scene or a render that failed half-way leaves something to clear here.
-    const uint32_t launch_words = hand_off ? (regen ? kCountStride : 1u) : 0u;
-    bool lanes_wait_pre = false;        // the lanes' launches of this call start behind what this call puts on the caller's stream first
-    if (!accumulate) {
-        if (!c->stats_clean) HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), st));
-        c->stats_clean = false;
-        HIP_TRY(hipEventRecord(c->ev_begin, st));
-        lanes_wait_pre = true;          // (the statistics' clearing -- here or at their collection -- is on that stream)
+    // ---- PLAN (pure; on a copy of the state)
+    ptsched::State next = c->sched;
+    const ptsched::Plan plan = ptsched::plan(next, job);
+    if (plan.profile) {
+        uint32_t top = 0;
+        for (const ptsched::Op& o : plan.ops) if (o.kind == ptsched::kOpRecord && o.event == ptsched::kEvPool) top = std::max(top, o.pool + 1u);
+        if ((rc = ensure_events(c, top))) return rc;
     }
-    for (int par = 0; par < (lanes ? kSets : two_sets ? 2 : 1); ++par)
-        if (launch_words && !c->counters_clean[par]) {
-            HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords + kCountStride * par, 0, kCountStride * sizeof(uint32_t), st));
-            c->counters_clean[par] = true;
-            lanes_wait_pre = true;
-        }
-    // A render that does NOT take the lanes (queue form, pixel lists, profiled or in-order renders) runs on the caller's stream and
-    // uses buffer sets 0 / 1 and their counters there.  Lane launches are ordered behind RESOLVES of lane launches only, so the
-    // first lanes render after such a render waits for the caller's stream as it stands now -- otherwise its launch could write
-    // the sample buffer a queued queue-form render has yet to resolve, or have its chunk counters cleared by that render's
-    // resolve (found by test_random_sequences_of_pipelined_renders_equal_isolated_renders: 3 % of a film's samples lost).
-    if (lanes && c->stream_work_since_lanes) lanes_wait_pre = true;
-    c->stream_work_since_lanes = !lanes;
-    if (lanes && lanes_wait_pre) HIP_TRY(hipEventRecord(c->ev_pre, st));
-    bool lane_waited_pre[kLanes] = {};
-    uint32_t launches = 0;
-    const uint32_t ev0 = c->profiled_batches;      // first free event slot
-    uint32_t primary_count = 0;
 
-    hipStream_t side = overlap ? c->side_stream : st;
-    if (overlap) {      // the side stream starts after whatever the caller's stream holds so far (previous renders, film state)
-        HIP_TRY(hipEventRecord(c->ev_l0[0], st));
-        HIP_TRY(hipStreamWaitEvent(side, c->ev_l0[0], 0));
-    }
-    for (uint32_t batch = 0; batch < n_batches; ++batch) {
-        const uint32_t s0 = batch * nb_max;
-        const uint32_t nb = std::min(nb_max, spp - s0);
-        int par = overlap ? (int)(batch & 1u) : 0;                // buffer set of this batch
-        int lane = 0;                                             // ... and, with lanes, the stream its launch goes to
-        if (lanes) {
-            par = (int)c->set_next; c->set_next = (c->set_next + 1u) % (uint32_t)kSets;
-            lane = (int)c->lane_next; c->lane_next = (c->lane_next + 1u) % (uint32_t)kLanes;
+    // ---- EXECUTE
+    std::vector<uint32_t> primary_events;
+    uint32_t pool_begin = 0;
+    auto exec = [&](const ptsched::Op& o, size_t index) -> int {
+        using namespace ptsched;
+        if (c->debug_fail_at >= 0 && (size_t)c->debug_fail_at == index) {
+            c->debug_fail_at = -1;
+            return fail(PT_ERR_HIP, "injected failure at stream operation %zu of the render (pt_debug_fail_after)", index);
         }
-        DevBuf<ptk::Rgb>& lsamp_buf = par == 3 ? c->lsamp4 : par == 2 ? c->lsamp3 : par ? c->lsamp2 : c->lsamp;
-        if (lanes && (rc = lsamp_buf.ensure(n_paths_max))) return rc;
-        ptk::Rgb* const lsamp_b = lsamp_buf.p;
-        a.s_base = prm->spp_offset + s0;
-        a.lsamp = lsamp_b;
-        // batch k reuses the sample buffer and overflow queue of batch k - 2: wait until its tail is through
-        if (overlap && batch >= 2) HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[par], 0));
-        uint32_t* const d_count = c->ovf_count.p + kStatsWords + kCountStride * par;   // [0] leftovers handed over, [64 ...] chunk counters of k_paths_regen
-        // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
-        // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
-        // (a regenerating launch whose waves run dry themselves leaves nothing for a continuation launch)
-        const uint32_t n_levels = hand_off && !(regen && regen_export <= 1u) ? 2u : 1u;
-        for (uint32_t level = 0; level < n_levels; ++level) {
-            hipStream_t ls = level == 0 ? st : side;
-            if (lanes) {
-                // this lane's stream: behind the resolve that read the lane's sample buffer last (two batches ago), and
-                // behind this call's fills on the caller's stream, if any -- not behind the caller's stream as such
-                ls = c->lane_stream[lane];
-                if (c->set_used[par]) HIP_TRY(hipStreamWaitEvent(ls, c->set_free[par], 0));      // (the resolve of kSets batches ago)
-                if (lanes_wait_pre && !lane_waited_pre[lane]) { HIP_TRY(hipStreamWaitEvent(ls, c->ev_pre, 0)); lane_waited_pre[lane] = true; }
-                // ... and not before the previous lane's launch has been handed to the device: two launches that become
-                // ready at the same moment would share the device from the start and run dry together
-                const int prev_lane = (lane + kLanes - 1) % kLanes;       // the lane of the launch before this one
-                if (c->lane_used[prev_lane]) HIP_TRY(hipStreamWaitEvent(ls, c->lane_begun[prev_lane], 0));
-                HIP_TRY(hipEventRecord(c->lane_begun[lane], ls));
-                c->lane_used[lane] = true;
-            }
-            const bool own = overlap && level > 0;       // continuation launch of an overlapped batch: its own queue
-            uint32_t g = grid;
+        hipStream_t s = sched_stream(c, st, o.stream);
+        switch (o.kind) {
+        case kOpHostSync:
+            for (int k = 0; k < kLanes; ++k) HIP_TRY(hipStreamSynchronize(c->lane_stream[k]));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (int r2 = c->xchg.ensure((size_t)next.xchg_stride * kLanes)) return r2;
+            return PT_OK;
+        case kOpMemsetStats:
+            HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), s));
+            return PT_OK;
+        case kOpMemsetCounters:
+            HIP_TRY(hipMemsetAsync(c->ovf_count.p + kStatsWords + kCountStride * o.set, 0, kCountStride * sizeof(uint32_t), s));
+            return PT_OK;
+        case kOpRecord:
+            if (o.event == kEvPool && !(o.pool & 1u)) pool_begin = o.pool;
+            HIP_TRY(hipEventRecord(sched_event(c, o), s));
+            return PT_OK;
+        case kOpWait:
+            HIP_TRY(hipStreamWaitEvent(s, sched_event(c, o), 0));
+            return PT_OK;
+        case kOpPost:
+            __atomic_store_n(c->h_posted, o.seq, __ATOMIC_RELEASE);      // before the launch is handed to the device
+            return PT_OK;
+        case kOpLaunch: {
+            const uint32_t s0 = o.batch * nb_max, nb = std::min(nb_max, spp - s0);
+            uint32_t* const d_count = c->ovf_count.p + kStatsWords + kCountStride * o.set;   // [0] leftovers handed over, [64 ...] chunk counters of k_paths_regen
+            const bool own = o.own_queue != 0;
+            a.s_base = prm->spp_offset + s0;
+            a.lsamp = sample_buffer(c, o.set).p;
+            // Level 0 traces the batch's paths (every bounce, see k_paths); in a large batch its waves hand their sparse
+            // tails to the overflow queue, which level 1 -- same kernel, fixed grid, count read on the device -- finishes.
+            // (a regenerating launch whose waves run dry themselves leaves nothing for a continuation launch)
             a.n_first = np * nb;
             a.n_first_dev = nullptr;
             a.seg_cap = ((((a.n_first + 63u) / 64u) + nw - 1) / nw) * 64u;
             a.src_mode = inject ? 1u : 0u;
             a.export_below = hand_off ? (small_scene ? export_small : ptk::kBlock) : 1u;
-            if (level > 0) {
-                g = cont_grid;
+            if (o.level > 0) {
                 a.n_first = 0; a.n_first_dev = d_count;
                 a.seg_cap = seg_cap_cont;
                 a.src_mode = 1u;
@@ -953,81 +922,78 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             a.sray1 = own ? c->csray[1].p : c->bvh_sray[1].p;
             for (int k = 0; k < 4; ++k) {
                 a.q.q[k] = own ? c->cqueue[k].p : c->queue[k].p;
-                // (with lanes nothing is ever handed over -- the waves run dry themselves --: the sets share one queue)
-                a.ovf_out.q[k] = hand_off ? c->ovf[lanes ? 0 : par][0][k].p : nullptr;
-                a.ovf_in.q[k] = inject ? const_cast<float4*>(list->inject[k]) : (hand_off ? c->ovf[lanes ? 0 : par][0][k].p : nullptr);
+                a.ovf_out.q[k] = hand_off ? c->ovf[o.ovf_par][0][k].p : nullptr;
+                a.ovf_in.q[k] = inject ? const_cast<float4*>(list->inject[k]) : (hand_off ? c->ovf[o.ovf_par][0][k].p : nullptr);
             }
             a.ovf_out_count = d_count;
-            a.debug_tag = (uint32_t)par;
+            a.debug_tag = o.set;
             a.chunk_counter = nullptr;
             a.xchg = nullptr;
             a.posted = nullptr; a.seq = 0; a.core_blocks = 0;
-            if (level == 0 && regen) {
+            a.regen_static = 0;
+            if (o.flags & kLaunchRegen) {
                 a.chunk_counter = d_count + ptk::kRegenCounterStride;
-                if (split) a.xchg = c->xchg.p + (lanes ? (size_t)lane * xchg_lane : 0);
+                if (o.flags & kLaunchSplit) a.xchg = c->xchg.p + o.xchg_off;
                 a.export_below = regen_export;
-                g = std::min<uint32_t>(regen_grid, (chunks_max + kWavesPerBlock - 1) / kWavesPerBlock);
-                // the first kRegenStatic16 / 16 of the chunks are dealt statically
-                const uint32_t nwr = g * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;
-                // (none with lanes: a workgroup of this launch that only finds room when the previous launch's last waves end
-                // would carry its dealt share as a serial tail)
-                a.regen_static = lanes ? 0u : (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
-                if (regen_core && regen_core < g) {              // spare workgroups beyond the core (see above)
-                    a.posted = c->d_posted;
-                    a.seq = ++c->lane_seq;
-                    a.core_blocks = regen_core;
-                    __atomic_store_n(c->h_posted, c->lane_seq, __ATOMIC_RELEASE);      // before the launch is handed to the device
-                }
+                // the first kRegenStatic16 / 16 of the chunks are dealt statically (none with lanes: a workgroup of this launch that
+                // only finds room when the previous launch's last waves end would carry its dealt share as a serial tail)
+                const uint32_t nwr = o.grid * kWavesPerBlock, nch = (a.n_first + 63u) / 64u;
+                if (o.flags & kLaunchStaticDeal) a.regen_static = (uint32_t)(((uint64_t)nch * kRegenStatic16 / 16) / nwr) * nwr;
+                if (o.core) { a.posted = c->d_posted; a.seq = o.seq; a.core_blocks = o.core; }
             }
-            if (hand_off) c->counters_clean[par] = false;       // until this batch's resolve has cleared them again
-            if (profile) {
-                if ((rc = ensure_events(c, 2 * (size_t)(ev0 + launches + 1)))) return rc;
-                HIP_TRY(hipEventRecord(c->ev_pool[2 * (ev0 + launches)], ls));
-            }
-            if (prm->exact_math) ptk::launch_paths_exact(a, g, ls);
-            else ptk::launch_paths_fast(a, g, ls);
-            if (profile) HIP_TRY(hipEventRecord(c->ev_pool[2 * (ev0 + launches) + 1], ls));
+            if (prm->exact_math) ptk::launch_paths_exact(a, o.grid, s);
+            else ptk::launch_paths_fast(a, o.grid, s);
             HIP_TRY(hipGetLastError());
-            if (level == 0) { ++primary_count; if (profile) c->primary_events.push_back(ev0 + launches); }
-            ++launches;
-            if (overlap && level == 0) {     // the tail of this batch (side stream) starts when its level-0 launch is through
-                HIP_TRY(hipEventRecord(c->ev_l0[par], st));
-                HIP_TRY(hipStreamWaitEvent(side, c->ev_l0[par], 0));
-            }
-            if (lanes) {                     // the resolve (caller's stream) starts when the lane's launch is through
-                HIP_TRY(hipEventRecord(c->lane_done[lane], ls));
-                HIP_TRY(hipStreamWaitEvent(st, c->lane_done[lane], 0));
-            }
+            if ((o.flags & kLaunchPrimary) && plan.profile) primary_events.push_back(pool_begin / 2u);
+            return PT_OK;
         }
-        ptk::ResolveArgs r{};
-        r.lsamp = lsamp_b;
-        r.film = c->film.p;
-        r.out_linear = d_linear;
-        r.out_rgba = d_rgba;
-        r.np = np; r.nb = nb;
-        r.load_film = batch > 0 || fs.load;
-        r.store_film = batch + 1 < n_batches || fs.store;
-        r.finalize = batch + 1 == n_batches;
-        r.spp_div = fs.div ? fs.div : spp;
-        r.out_packed = d_packed;
-        if (launch_words) { r.zero_words = d_count; r.n_zero = launch_words; }
-        ptk::launch_resolve(r, side);
-        HIP_TRY(hipGetLastError());
-        if (launch_words) c->counters_clean[par] = true;
-        if (overlap) HIP_TRY(hipEventRecord(c->ev_resolved[par], side));
-        if (lanes) { HIP_TRY(hipEventRecord(c->set_free[par], st)); c->set_used[par] = true; }
-    }
-    if (overlap)        // the caller's stream is complete when the last resolve is (the side stream is in order)
-        HIP_TRY(hipStreamWaitEvent(st, c->ev_resolved[(n_batches - 1) & 1u], 0));
-    HIP_TRY(hipEventRecord(c->ev_end, st));
-    // (the device-side statistics are read when they are collected -- pt_sync --, not copied back per render)
-    c->stats.samples += (uint64_t)np * spp;
-    c->stats.bounce_launches += launches;
-    c->stats.batches += n_batches;
-    c->stats.primary_launches += primary_count;
+        case kOpResolve: {
+            const uint32_t s0 = o.batch * nb_max, nb = std::min(nb_max, spp - s0);
+            ptk::ResolveArgs r{};
+            r.lsamp = sample_buffer(c, o.set).p;
+            r.film = c->film.p;
+            r.out_linear = d_linear;
+            r.out_rgba = d_rgba;
+            r.np = np; r.nb = nb;
+            r.load_film = o.batch > 0 || fs.load;
+            r.store_film = o.batch + 1 < n_batches || fs.store;
+            r.finalize = o.batch + 1 == n_batches;
+            r.spp_div = fs.div ? fs.div : spp;
+            r.out_packed = d_packed;
+            if (o.zero_words) { r.zero_words = c->ovf_count.p + kStatsWords + kCountStride * o.set; r.n_zero = o.zero_words; }
+            ptk::launch_resolve(r, s);
+            HIP_TRY(hipGetLastError());
+            return PT_OK;
+        }
+        default:
+            return fail(PT_ERR_HIP, "internal: unknown stream operation %u", o.kind);
+        }
+    };
+    for (size_t i = 0; i < plan.ops.size(); ++i)
+        if ((rc = exec(plan.ops[i], i))) {
+            const std::string keep = g_err;
+            sched_recover(c, st, next);
+            g_err = keep;
+            return rc;
+        }
 
-    if (profile) c->profiled_batches = ev0 + launches;
-    c->stats_pending = true;
+    // ---- COMMIT
+    if (!plan.accumulate) begin_period();
+    c->sched = next;
+    // (the device-side statistics are read when they are collected -- pt_sync --, not copied back per render)
+    if (job.capturing) {
+        // nothing ran, and the graph may be replayed any number of times: the device will have counted a multiple of these
+        const uint64_t n = (uint64_t)np * spp;
+        uint64_t x = c->capture_gcd, y = n;
+        while (y) { const uint64_t t = x % y; x = y; y = t; }
+        c->capture_gcd = x;
+    } else {
+        c->expected_samples += (uint64_t)np * spp;
+    }
+    c->stats.bounce_launches += plan.launches;
+    c->stats.batches += n_batches;
+    c->stats.primary_launches += plan.primary_launches;
+    c->primary_events.insert(c->primary_events.end(), primary_events.begin(), primary_events.end());
     return PT_OK;
 }
 
@@ -1054,31 +1020,54 @@ int pt_sync(PtContext* c) {
     if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->set_next = 0; c->lane_next = 0;       // everything enqueued so far is complete: the buffer sets and lanes start over
-    if (c->stats_pending) {
+    const bool collect = c->sched.stats_pending != 0;
+    bool cleared = false;
+    int rc = PT_OK;
+    if (collect) {
         // the device-side statistics of the renders since the last collection: read now (the stream is idle) and cleared
         // for the next ones, so that no render carries a copy or a fill of them in its stream
         HIP_TRY(hipMemcpy(c->h_dstats, c->ovf_count.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        c->stats_clean = hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), c->stream) == hipSuccess;
+        cleared = hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), c->stream) == hipSuccess;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) c->stats.total_ms = ms;
+        (void)hipGetLastError();          // (events recorded into a graph have no time)
         double kms = 0.0;
-        for (uint32_t b = 0; b < c->profiled_batches; ++b)
+        for (uint32_t b = 0; b < c->sched.profiled; ++b)
             if (hipEventElapsedTime(&ms, c->ev_pool[2 * b], c->ev_pool[2 * b + 1]) == hipSuccess) kms += ms;
         c->stats.bounce_kernel_ms = kms;
         c->stats.shadow_rays = c->h_dstats[0];
         c->stats.vertices = c->h_dstats[1];
         c->stats.primary_vertices = c->h_dstats[3];
         double pms = 0.0;
-        if (c->profiled_batches)
+        if (c->sched.profiled)
             for (uint32_t li : c->primary_events)
                 if (hipEventElapsedTime(&ms, c->ev_pool[2 * li], c->ev_pool[2 * li + 1]) == hipSuccess) pms += ms;
         c->stats.primary_kernel_ms = pms;
         c->stats.max_depth_reached = (uint32_t)c->h_dstats[2];
-        c->stats_pending = false;
+        // PtStats.samples is what the DEVICE counted: a path adds one where its radiance is written to the sample buffer
+        // (stats[4]).  The host's own arithmetic -- tile pixels x spp of every render enqueued -- is the expectation; a render
+        // that lost or repeated work (a scheduling race, a counter cleared under a running launch) shows up here, not in a film
+        // somebody has to look at.  Renders captured into graphs ran zero or more times: multiples of their size are accepted.
+        const uint64_t dev = c->h_dstats[4], exp = c->expected_samples;
+        c->stats.samples = dev;
+        c->stats.samples_expected = exp;
+        bool ok = dev == exp;
+        if (!ok && c->capture_gcd) ok = dev >= exp && (dev - exp) % c->capture_gcd == 0;
+        c->expected_samples = 0;
         if (c->h_dstats[7] != 0)     // a kernel found one of its own invariants violated: the film is not to be trusted
-            return fail(PT_ERR_HIP, "internal: the exchange stacks of k_paths_regen_split overflowed (please report; PtTuning.level0_form = 1 avoids the kernel)");
+            rc = fail(PT_ERR_HIP, "internal: the exchange stacks of k_paths_regen_split overflowed (please report; PtTuning.level0_form = 1 avoids the kernel)");
+        else if (!ok)
+            rc = fail(PT_ERR_HIP, "internal: the device finished %llu samples where the renders since the last collection asked for %llu "
+                                  "(please report; the films of these renders are not to be trusted)", (unsigned long long)dev, (unsigned long long)exp);
     }
+    ptsched::on_sync(c->sched, collect, cleared);      // everything enqueued so far is complete: the buffer sets and lanes start over
+    return rc;
+}
+
+// Test hook: the n-th stream operation (0-based) of the NEXT render on this context fails as if its HIP call had; < 0: none.
+int pt_debug_fail_after(PtContext* c, int64_t n) {
+    if (!c) return fail(PT_ERR_INVALID_ARG, "null context");
+    c->debug_fail_at = n;
     return PT_OK;
 }
 

@@ -105,7 +105,7 @@ struct BounceArgs {
     float4* sray0;            // shadow ray (o, d.x)
     float4* sray1;            // (d.y, d.z, t_max, 1 = the slot has a shadow ray)
     Rgb* lsamp;               // per-path final radiance, index = s_local*np + tile_row*width + x
-    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)  [3] vertices of level-0 launches  [7] internal error flag (k_paths_regen_split: exchange stacks met)
+    unsigned long long* stats;  // [0] shadow rays  [1] path vertices  [2] deepest vertex (max)  [3] vertices of level-0 launches  [4] finished samples (lsamp writes)  [7] internal error flag (k_paths_regen_split: exchange stacks met)
     TileMap tile;
     SceneView sc;
     CameraF cam;

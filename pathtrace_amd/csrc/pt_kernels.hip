@@ -645,6 +645,7 @@ k_paths(BounceArgs a) {
     const uint32_t W = a.film_w;
     uint32_t n_in = 0;                     // wave-uniform: queued paths of this wave's segment
     uint32_t wave_shadow = 0, wave_vertices = 0;
+    uint32_t wave_samples = 0;             // wave-uniform: paths whose radiance this wave has written to lsamp (finished samples)
     uint32_t wave_depth = 0;               // wave-uniform: deepest vertex this wave has processed
     constexpr bool from_overflow = OVF;
 
@@ -744,6 +745,7 @@ k_paths(BounceArgs a) {
 
         // ---- retire, or compact in place into the wave's own segment
         if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
+        wave_samples += (uint32_t)__popcll(__ballot(active && !alive));
         const unsigned long long mask = __ballot(alive);
         uint32_t cnt_before = 0, cnt_all = (uint32_t)__popcll(mask);
         if (!SMALL) {
@@ -792,6 +794,7 @@ k_paths(BounceArgs a) {
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);   // level-0 launches only
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
+        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
     }
 }
 
@@ -819,6 +822,27 @@ k_paths(BounceArgs a) {
 //     sample has its own slot of lsamp, and the statistics are sums.
 // Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 79 VGPRs
 // (6 waves per SIMD), the generic one 93 (5; reached only with PtTuning.level0_form = 2).
+// Finished samples are counted where their radiance is written (stats[4]; pt_sync compares the sum with pixels x spp).  The
+// regenerating kernels have no scalar register left for one more wave-uniform counter (106 of 106 SGPRs: it would cost the
+// split form two more spilled VGPRs), so a lane keeps its count in the high half of the word that holds the deepest vertex
+// of the paths it finished (depth < 65535, vertex_end).  A lane cannot finish more paths than enter its wave, 64 per ring
+// refill, so the refill loop is where the count is checked for overflow (fin_flush_if_full).
+PT_DEV void note_finished(uint32_t& fin, uint32_t depth) {
+    const uint32_t d = fin & 0xFFFFu;
+    fin = (fin & 0xFFFF0000u) + 0x10000u + (depth > d ? depth : d);
+}
+PT_DEV void fin_flush_if_full(uint32_t& fin, unsigned long long* stats) {
+    if (fin >= 0x80000000u) { atomicAdd(&stats[4], (unsigned long long)(fin >> 16)); fin &= 0xFFFFu; }
+}
+// end of the wave: lane 0 gets (sum of the lanes' counts, max of their depths)
+PT_DEV void fin_reduce(uint32_t fin, uint32_t& count, uint32_t& dmax) {
+    count = fin >> 16; dmax = fin & 0xFFFFu;
+    for (int off = 32; off > 0; off >>= 1) {
+        count += (uint32_t)__shfl_xor((int)count, off);
+        const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off);
+        dmax = w2 > dmax ? w2 : dmax;
+    }
+}
 constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
 // Workgroup size of k_paths_regen.  Its waves share nothing but the LDS copy of the scene, so a workgroup could be ONE wave --
 // a wave that ends would free a slot the next launch (pt_api.cpp, lanes) can take at once, where a four-wave workgroup needs
@@ -885,7 +909,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
     uint32_t pool_head = 0, pool_cnt = 0;  // wave-uniform: ring read position, entries
     bool exhausted = false;                // wave-uniform: the batch has no more chunks
     uint32_t wave_shadow = 0, wave_vertices = 0;
-    uint32_t dmax = 0;                     // per lane: deepest vertex of the paths this lane finished
+    uint32_t fin = 0;                      // per lane: paths this lane finished << 16 | their deepest vertex (note_finished)
     PathState p = parked_state();
     bool alive = false;
 #if PT_DRAIN_MAIL
@@ -938,6 +962,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
                 pool_s[e] = s_local << 16;
             }
             pool_cnt += valid;
+            fin_flush_if_full(fin, a.stats);
         }
         __builtin_amdgcn_wave_barrier();
 #if PT_DRAIN_PRIO == 1
@@ -1077,7 +1102,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
         alive = vertex_end<MIS, DIFFUSE, true>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
         if (active && !alive) {
             a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
-            dmax = p.depth > dmax ? p.depth : dmax;
+            note_finished(fin, p.depth);
             p.o = parked_origin(); p.d = parked_dir();  // until the lane gets its next path (end of the batch: for good)
         }
     }
@@ -1093,16 +1118,19 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
             if (alive) {
                 store_state(a.ovf_out, base + lane_rank(mask), p);
                 const uint32_t done = p.depth ? p.depth - 1u : 0u;   // deepest vertex it has been through (0: none yet)
-                dmax = done > dmax ? done : dmax;
+                const uint32_t d = fin & 0xFFFFu;
+                fin = (fin & 0xFFFF0000u) | (done > d ? done : d);
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off); dmax = w2 > dmax ? w2 : dmax; }
+    uint32_t wave_samples, dmax;
+    fin_reduce(fin, wave_samples, dmax);
     if (lane == 0u) {
         if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
+        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
 #ifdef PT_DRAIN_TIMING      // stats[8..12] (beyond the 8 words the host reads): ~begin (min), ~exhausted (min), exhausted (max), end (max), sum of per-wave drain times
         const unsigned long long t_end = wall_clock64();
         if (t_exhausted == 0ull) t_exhausted = t_end;
@@ -1200,7 +1228,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     uint32_t sq_cnt = 0, pq_cnt = 0;       // wave-uniform: special entries [0, sq_cnt), plain entries [kXq - pq_cnt, kXq)
     bool overflow = false;                 // wave-uniform: the stacks met (cannot happen, see above; reported instead of corrupting paths)
     uint32_t wave_shadow = 0, wave_vertices = 0;
-    uint32_t dmax = 0;
+    uint32_t fin = 0;                      // per lane: paths finished << 16 | their deepest vertex (note_finished)
     PathState p = parked_state();
     bool alive = false;
 
@@ -1234,6 +1262,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 pool_s[e] = s_local << 16;
             }
             pool_cnt += valid;
+            fin_flush_if_full(fin, a.stats);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- lanes without a path: first the plain stack (paths that left a Mirror surface), then the ring
@@ -1313,7 +1342,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
             alive = vertex_end<MIS, PLAIN, true>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
             if (active && !alive) {
                 a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
-                dmax = p.depth > dmax ? p.depth : dmax;
+                note_finished(fin, p.depth);
                 p.o = parked_origin(); p.d = parked_dir();
             }
         }
@@ -1381,7 +1410,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
                 if (qa && !qalive) {
                     a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
-                    dmax = q.depth > dmax ? q.depth : dmax;
+                    note_finished(fin, q.depth);
                 }
                 // the survivors' next vertex: Mirror again (a path inside the sphere) or not?
 #if !PT_SPLIT_PARK_LDS
@@ -1427,12 +1456,14 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
         }
     }
 
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off); dmax = w2 > dmax ? w2 : dmax; }
+    uint32_t wave_samples, dmax;
+    fin_reduce(fin, wave_samples, dmax);
     if (lane == 0u) {
         if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
+        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
         if (overflow) atomicMax(&a.stats[7], 1ull);      // pt_sync turns it into an error
     }
 }
@@ -1698,7 +1729,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
     float4* const aux = a.aux + seg_base;
     float4* const sr0 = a.sray0 + seg_base;
     float4* const sr1 = a.sray1 + seg_base;
-    uint32_t wave_shadow = 0, wave_vertices = 0, wave_depth = 0;
+    uint32_t wave_shadow = 0, wave_vertices = 0, wave_depth = 0, wave_samples = 0;
 
     // ---- the wave's share of the batch -> its segment (chunk k of the batch belongs to wave k % nw)
     uint32_t n_in = 0;
@@ -1781,6 +1812,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             const bool visible = MIS && v.need_shadow && h.z == 0.0f;
             const bool alive = vertex_end<MIS, DIFFUSE, false>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
             if (active && !alive) a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
+            wave_samples += (uint32_t)__popcll(__ballot(active && !alive));
             const unsigned long long mask = __ballot(alive);
             if (alive) store_state(q, out_n + lane_rank(mask), p);
             out_n += (uint32_t)__popcll(mask);
@@ -1804,6 +1836,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
         if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
         if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
         if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
+        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
     }
 }
 

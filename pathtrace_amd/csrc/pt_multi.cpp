@@ -214,6 +214,17 @@ int sync_exchange(PtMulti* m) {
 // the `sent` events after it.
 int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderParams& prm, const FrameShape& fs, uint64_t frame,
                    bool defer_gather) {
+    // Exchange by copies: the host latches count FRAMES and must advance whatever happens in here -- a frame whose render was
+    // refused (spp = 0, a tile larger than max_paths_in_flight, out of memory) or whose enqueue failed half-way still "copies"
+    // and is still "unpacked" as far as the latches go, or the next frame's enqueue would wait for it for ever.
+    struct Latch {
+        PtMulti* m; uint32_t g; uint64_t frame;
+        ~Latch() {
+            if (!m->copy) return;
+            { std::lock_guard<std::mutex> lk(m->lat_mu); if (m->copied_frame[g] < frame) m->copied_frame[g] = frame; }
+            m->lat_cv.notify_all();
+        }
+    } latch{m, g, frame};
     HIP_TRY(hipSetDevice(m->devices[g]));
     PtRenderParams p = prm;
     p.band_rows = fs.band_rows; p.band_index = g; p.band_count = fs.n;
@@ -241,8 +252,7 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
         else HIP_TRY(hipMemcpyPeerAsync(dst, m->devices[0], m->packed[slot].p, m->devices[g], fs.tile_px * 16, xs));
         HIP_TRY(hipEventRecord(m->ev_copied[g], xs));
         HIP_TRY(hipEventRecord(m->ev_sent[slot], xs));
-        { std::lock_guard<std::mutex> lk(m->lat_mu); m->copied_frame[g] = frame; }
-        m->lat_cv.notify_all();
+        // (copied_frame[g] = frame: the latch above, on every way out)
     } else if (!defer_gather) {
         // this device's call of THE gather (ncclGather, rccl.h:745): its communicator, its exchange stream, its thread
         NCCL_TRY(g_rccl.Gather(m->packed[slot].p, m->recv.p, fs.tile_px * 16, ncclUint8, 0, m->comm[g], xs));
@@ -254,6 +264,14 @@ int enqueue_device(PtMulti* m, uint32_t g, const PtCamera& cam, const PtRenderPa
 
 // The root's tail of a frame: rows into image order, behind the gather in the root's exchange stream
 int enqueue_root_tail(PtMulti* m, const FrameShape& fs, uint64_t frame, float* d_linear, uint8_t* d_rgba) {
+    struct Latch {             // as in enqueue_device: the frame counts as unpacked on every way out
+        PtMulti* m; uint64_t frame;
+        ~Latch() {
+            if (!m->copy) return;
+            { std::lock_guard<std::mutex> lk(m->lat_mu); if (m->unpacked_frame < frame) m->unpacked_frame = frame; }
+            m->lat_cv.notify_all();
+        }
+    } latch{m, frame};
     HIP_TRY(hipSetDevice(m->devices[0]));
     hipStream_t st = m->xs[0];
     if (m->copy) {
@@ -265,11 +283,7 @@ int enqueue_root_tail(PtMulti* m, const FrameShape& fs, uint64_t frame, float* d
     }
     ptk::launch_film_unpack(m->recv.p, fs.W, fs.H, fs.band_rows, fs.n, fs.max_rows, d_linear, d_rgba, st);
     HIP_TRY(hipGetLastError());
-    if (m->copy) {
-        HIP_TRY(hipEventRecord(m->ev_unpacked, st));
-        { std::lock_guard<std::mutex> lk(m->lat_mu); m->unpacked_frame = frame; }
-        m->lat_cv.notify_all();
-    }
+    if (m->copy) HIP_TRY(hipEventRecord(m->ev_unpacked, st));
     return PT_OK;
 }
 
@@ -438,8 +452,9 @@ int pt_multi_set_exchange(PtMulti* m, uint32_t mode) {
     return PT_OK;
 }
 
-// 1: one host thread per device feeds its stream (default for more than one device); 0: the calling thread enqueues every
-// device in turn and the gather calls form one ncclGroup.  Same frame either way.
+// 0 (default): the calling thread enqueues every device in turn and the gather calls form one ncclGroup; 1: one host thread per
+// device feeds its stream.  Same frame either way.  (Both forms have only ever run with all contexts on ONE device or over one
+// rank: no multi-GPU node was available in rounds 1-5.)
 int pt_multi_set_threads(PtMulti* m, int enabled) {
     if (!m) return pt_internal_fail(PT_ERR_INVALID_ARG, "null multi-device object");
     int rc = multi_drain(m);
@@ -531,8 +546,11 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
             m->feeder->post(g, [=](std::string& err) -> int {
                 const auto t0 = std::chrono::steady_clock::now();
                 int r = enqueue_device(m, g, cam_v, prm_v, fs, frame, false);
-                if (!r && g == 0) r = enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
                 if (r) err = pt_last_error();
+                if (g == 0) {              // the row permutation also behind a failed render: the frame's bookkeeping must complete
+                    const int r2 = enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
+                    if (!r && r2) { r = r2; err = pt_last_error(); }
+                }
                 timed(g, t0);
                 return r;
             });
@@ -540,9 +558,14 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
         return PT_OK;
     }
     // one thread: 1. every device renders its interleaved bands into its send buffer (no collective on the data path)
+    // (a device whose render is refused does not stop the frame: the others still render, the exchange and the row permutation
+    // still run -- every device takes part in the gather, every latch advances -- and the first error is returned at the end)
+    int first_rc = PT_OK;
+    std::string first_err;
     for (uint32_t g = 0; g < n; ++g) {
         const auto t0 = std::chrono::steady_clock::now();
-        if ((rc = enqueue_device(m, g, cam_v, prm_v, fs, frame, true))) return rc;
+        rc = enqueue_device(m, g, cam_v, prm_v, fs, frame, true);
+        if (rc && !first_rc) { first_rc = rc; first_err = pt_last_error(); }
         timed(g, t0);
     }
     // 2. ONE gather of the padded tiles to the first device (ncclGather, rccl.h:745), every device on its exchange stream
@@ -560,7 +583,9 @@ int pt_multi_render_device(PtMulti* m, const PtCamera* cam, const PtRenderParams
         }
     }
     // 3. rows into image order on the first device
-    return enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
+    rc = enqueue_root_tail(m, fs, frame, d_linear, d_rgba);
+    if (first_rc) return pt_internal_fail(first_rc, "%s", first_err.c_str());
+    return rc;
 }
 
 int pt_multi_sync(PtMulti* m) {
@@ -590,6 +615,7 @@ int pt_multi_get_stats(PtMulti* m, PtStats* out) {
         t.bounce_kernel_ms = std::max(t.bounce_kernel_ms, s.bounce_kernel_ms); t.total_ms = std::max(t.total_ms, s.total_ms);
         t.primary_vertices += s.primary_vertices; t.primary_kernel_ms = std::max(t.primary_kernel_ms, s.primary_kernel_ms);
         t.primary_launches += s.primary_launches;
+        t.samples_expected += s.samples_expected;
     }
     *out = t;
     return PT_OK;

@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const PT_ABI_VERSION: u32 = 3;
+pub const PT_ABI_VERSION: u32 = 4;
 
 pub const PT_OK: c_int = 0;
 pub const PT_ERR_INVALID_ARG: c_int = 1;
@@ -92,6 +92,7 @@ pub struct PtStats {
     pub primary_kernel_ms: f64,
     pub primary_launches: u32,
     pub reserved2: u32,
+    pub samples_expected: u64,
 }
 
 /// `pt_multi_info`: what a multi-device object is made of.
@@ -118,6 +119,54 @@ pub struct PtContext {
 #[repr(C)]
 pub struct PtMulti {
     _private: [u8; 0],
+}
+/// The launch scheduler on a state of its own (host only; `pt_debug_sched_*`, tests).
+#[repr(C)]
+pub struct PtSched {
+    _private: [u8; 0],
+}
+/// A render as the scheduler sees it (`csrc/pt_sched.h`: `Job`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtSchedJob {
+    pub n_batches: u32,
+    pub regen: u32,
+    pub split: u32,
+    pub hand_off: u32,
+    pub regen_export: u32,
+    pub profile: u32,
+    pub in_order: u32,
+    pub capturing: u32,
+    pub grid: u32,
+    pub regen_grid: u32,
+    pub cont_grid: u32,
+    pub regen_capacity: u32,
+    pub fixed_grid: u32,
+    pub counter_words: u32,
+    pub xchg_need: u64,
+}
+/// One stream operation of a planned render (`csrc/pt_sched.h`: `Op`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PtSchedOp {
+    pub kind: u32,
+    pub stream: u32,
+    pub event: u32,
+    pub pool: u32,
+    pub set: u32,
+    pub lane: u32,
+    pub level: u32,
+    pub own_queue: u32,
+    pub ovf_par: u32,
+    pub batch: u32,
+    pub grid: u32,
+    pub seq: u32,
+    pub core: u32,
+    pub flags: u32,
+    pub zero_words: u32,
+    pub reserved: u32,
+    pub xchg_off: u64,
+    pub xchg_len: u64,
 }
 
 /// `pt_context_set_stream`: HIP's legacy default stream (its handle, 0, means "the context's own stream").
@@ -156,6 +205,11 @@ extern "C" {
     pub fn pt_multi_info(m: *mut PtMulti, out: *mut PtMultiInfo) -> c_int;
     pub fn pt_debug_multi_create_shared(device: c_int, n: u32, out: *mut *mut PtMulti) -> c_int;
     pub fn pt_debug_feeder_selftest(n_workers: u32, n_frames: u32, spin: u32, fail_at: i32, order_out: *mut u64, n_out: *mut u32) -> c_int;
+    pub fn pt_debug_sched_create(out: *mut *mut PtSched) -> c_int;
+    pub fn pt_debug_sched_destroy(s: *mut PtSched);
+    pub fn pt_debug_sched_render(s: *mut PtSched, job: *const PtSchedJob, faults: u32, fail_after: u32, ops: *mut PtSchedOp, cap: u32, n_ops: *mut u32, lanes: *mut u32) -> c_int;
+    pub fn pt_debug_sched_sync(s: *mut PtSched, collect: u32) -> c_int;
+    pub fn pt_debug_fail_after(ctx: *mut PtContext, n: i64) -> c_int;
     pub fn pt_multi_scene_upload(m: *mut PtMulti, objs: *const PtObject, n_objs: u32) -> c_int;
     pub fn pt_multi_set_tuning(m: *mut PtMulti, tuning: *const PtTuning) -> c_int;
     pub fn pt_multi_render_device(m: *mut PtMulti, cam: *const PtCamera, params: *const PtRenderParams, d_linear_rgb: *mut f32, d_rgba8: *mut u8) -> c_int;
