@@ -156,6 +156,24 @@ def cpu_baseline(pt, objs, width, height, spp_full, desc):
     return out
 
 
+def counter_problems(tag, timed, want_samples, steps, ref=None, ref_steps=0):
+    """The device counters of a timed region of `steps` renders of a deterministic job -> list of problems (empty: fine).
+    timed: {"samples": finished samples counted on the device, "samples_expected": the library's own pixels x spp sum,
+    "vertices", "shadow_rays"}; ref: the same counters of `ref_steps` renders of the job run one by one (None: only
+    divisibility by `steps` can be checked)."""
+    problems = []
+    if timed["samples"] != want_samples or timed["samples_expected"] != want_samples:
+        problems.append(f"{tag}: the device finished {timed['samples']} samples, the library expected {timed['samples_expected']}, "
+                        f"{steps} renders of the job have {want_samples}")
+    for key in ("vertices", "shadow_rays"):
+        if ref is not None:
+            if timed[key] * ref_steps != ref[key] * steps:
+                problems.append(f"{tag}: {key} {timed[key]} != {steps} x the per-render {ref[key] / max(ref_steps, 1)}")
+        elif timed[key] % steps:
+            problems.append(f"{tag}: {key} {timed[key]} is not a multiple of {steps} renders")
+    return problems
+
+
 def profile_summary(world, workload, accel):
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 passes of THIS command
     (profiles/r03/roofline_<workload>[_bvh].json, written by tools/profile_workload.sh on the GPU box).  PMC counters
@@ -278,8 +296,12 @@ def main(argv=None):
     lin = torch.empty((rows, WIDTH, 3), dtype=torch.float32, device=dev)
     rgba = torch.empty((rows, WIDTH, 4), dtype=torch.uint8, device=dev)
 
-    acc = {"vertices": 0, "samples": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0,
+    acc = {"vertices": 0, "samples": 0, "samples_expected": 0, "bounce_ms": 0.0, "launches": 0, "total_ms": 0.0,
            "p_vertices": 0, "p_ms": 0.0, "p_launches": 0, "shadow_rays": 0}
+
+    def reset_acc():
+        for key in acc:
+            acc[key] = 0 if isinstance(acc[key], int) else 0.0
 
     # one process per GPU: the single exchange step of the path is one gather of the framebuffer (f32 + RGBA8 packed) per
     # step.  It is launched asynchronously, so the gather of step k runs (on the backend's stream) while step k + 1 renders;
@@ -313,7 +335,8 @@ def main(argv=None):
             st = ctx.stats()
             acc["vertices"] += st.vertices
             acc["shadow_rays"] += st.shadow_rays
-            acc["samples"] += st.samples
+            acc["samples"] += st.samples                        # counted on the DEVICE (PtStats.samples; pt_sync compares it with ...
+            acc["samples_expected"] += st.samples_expected      # ... pixels x spp of the renders enqueued and fails on a mismatch)
             acc["bounce_ms"] += st.bounce_kernel_ms
             acc["launches"] += st.bounce_launches
             acc["total_ms"] += st.total_ms
@@ -329,47 +352,65 @@ def main(argv=None):
         for d in (range(world) if mode == "multi" and not args.shared_device else [dev_index]):
             torch.cuda.synchronize(d)
 
-    frame = frame8 = None
-    for k in range(args.warmup):
-        step(k + 1 == args.warmup)
-    for key in acc:                             # the warm-up steps are not part of the statistics
-        acc[key] = 0 if isinstance(acc[key], int) else 0.0
+    def timed_region(n_warm):
+        """n_warm untimed steps, then EXACTLY args.steps timed steps between barrier + device synchronisation on both sides.
+        -> (seconds: max over ranks, device counters of the timed steps, the LAST timed frame as (linear, rgba8) clones on rank 0)"""
+        for k in range(n_warm):
+            step(k + 1 == n_warm)
+        reset_acc()                             # the warm-up steps are not part of the statistics
+        if dist_path:
+            film_gather.finish()
+        barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k + 1 == args.steps)
+        fr = fr8 = None
+        if dist_path:
+            fr, fr8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
+        device_sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_path:
+            t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        counters = dict(acc)
+        # the frame the LAST timed step produced, kept for the bitwise check below (later steps reuse the buffers)
+        if dist_path:
+            last = (fr.clone(), fr8.clone()) if rank == 0 else None
+        else:
+            last = (lin.clone(), rgba.clone())
+        return dt, counters, last
+
+    elapsed, timed, last_frame = timed_region(args.warmup)
+    # Single-process multi-device form: BOTH exchanges in the one run -- `value` with ONE ncclGather per frame (north_star's form),
+    # `config.exchange_copy` with one DMA copy per device in its place (pt_multi_set_exchange; no kernel takes part) -- so that the
+    # first run on a multi-GPU node settles the default by measurement.  Each with its own bitwise frame check.
+    copy_run = None
+    if mode == "multi" and not args.shared_device and args.exchange == "rccl":
+        ctx.set_exchange("copy")
+        c_elapsed, c_timed, c_last = timed_region(max(1, args.warmup))
+        copy_run = {"elapsed": c_elapsed, "timed": c_timed, "last": c_last}
+        ctx.set_exchange("rccl")
     if dist_path:
-        film_gather.finish()
-    barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k + 1 == args.steps)
-    if dist_path:
-        frame, frame8 = film_gather.finish()      # the last frame; earlier ones were completed by the next start()
-    device_sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_path:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([acc["vertices"], acc["samples"]], dtype=torch.float64, device=comm_dev)
+        tot = torch.tensor([timed["vertices"], timed["samples"]], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_samples = float(tot[1].item())
     else:
-        job_samples = float(acc["samples"])     # pt_multi_get_stats sums over the devices
+        job_samples = float(timed["samples"])   # pt_multi_get_stats sums over the devices
 
     post_pass = not args.in_order
     if post_pass:
         # launch times for the roofline: three more steps, in order, with HIP events around every launch, outside the timed region
         prm.profile = 1
-        for key in ("vertices", "shadow_rays", "bounce_ms", "launches", "total_ms", "p_vertices", "p_ms", "p_launches"):
-            acc[key] = 0 if isinstance(acc[key], int) else 0.0
-        keep_samples = acc["samples"]
+        reset_acc()
         async_was, async_steps = async_steps, False
         for k in range(3):
             step(True)
         if dist_path:
             film_gather.finish()
         async_steps = async_was
-        acc["samples"] = keep_samples // args.steps * 3
         prm.profile = 0
     prof_steps = 3 if post_pass else args.steps       # the steps acc's launch times and counters cover
     multi_info = ctx.info() if mode == "multi" else None
@@ -384,29 +425,54 @@ def main(argv=None):
         for _ in range(reps):
             h_lin, h_rgba = pt.render_host(cam, objs, pt.default_params(spp=spp))
         dt = (time.perf_counter() - t1) / reps
-        assert (h_lin == lin.cpu().numpy()).all() and (h_rgba == rgba.cpu().numpy()).all()     # same film as the device-resident step
+        assert (h_lin == last_frame[0].cpu().numpy()).all() and (h_rgba == last_frame[1].cpu().numpy()).all()     # same film as the device-resident step
         host_buffers = {"value": round(WIDTH * HEIGHT * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_render": round(dt * 1e3, 3),
                         "what": "pt_render(): scene upload + render + both film planes copied to host memory (PCIe), blocking; "
                                 f"mean of {reps} calls; film bitwise equal to the device-resident step's"}
 
+    # ---- the record verifies itself: the number above rests on overlapped launches, so
+    # (b) the DEVICE counters of the timed region must be exactly those of `steps` renders of the job -- samples counted where a
+    #     path's radiance is written (PtStats.samples; the library compares it with pixels x spp itself and fails pt_sync on a
+    #     mismatch), vertices and shadow rays = steps x the per-step figures of the in-order steps after the region (the job is
+    #     deterministic) -- and
+    # (c) the LAST timed frame must equal, bit for bit, the job rendered once, alone and in order, on one GPU by a context of its
+    #     own: in every mode and for every N.  Any difference -> the JSON line says so and the exit code is non-zero.
+    problems = []
+
+    want = rows * WIDTH * spp * args.steps          # this process's share of the job (multi: all devices, summed by the library)
+    per_step = acc if post_pass else None
+    problems += counter_problems("timed region", timed, want, args.steps, per_step, prof_steps)
+    if copy_run:
+        problems += counter_problems("timed region (exchange by copies)", copy_run["timed"], want, args.steps, per_step, prof_steps)
+    frame_ok = None
     if rank == 0:
-        if dist_path:
-            assert frame is not None and tuple(frame.shape) == (HEIGHT, WIDTH, 3) and torch.isfinite(frame).all()
-            if world == 1:
-                # --force-dist: the gathered frame is the plain render of the tile
-                ref_lin = torch.empty_like(lin); ref_rgba = torch.empty_like(rgba)
-                ctx.render_into(cam, prm, ref_lin.data_ptr(), ref_rgba.data_ptr())
-                ctx.sync()
-                assert torch.equal(frame, ref_lin) and torch.equal(frame8, ref_rgba)
-        else:
-            assert torch.isfinite(lin).all()
-        if mode == "multi" and world == 1:
-            # --force-multi: the frame that went through ncclGather + row permutation is the plain render, bit for bit
-            ref_ctx = pt.Context(0)
-            ref_ctx.upload(objs)
-            ref_lin, ref_rgba = ref_ctx.render(cam, pt.default_params(**common))
-            assert torch.equal(ref_lin, lin) and torch.equal(ref_rgba, rgba)
-            ref_ctx.close()
+        ref_ctx = pt.Context(dev_index)
+        ref_ctx.upload(objs)
+        ref_ctx.set_tuning(in_order=1)
+        ref_lin, ref_rgba = ref_ctx.render(cam, pt.default_params(spp=spp, max_paths_in_flight=args.max_paths, accel=args.accel))
+        ref_ctx.close()
+
+        def same(fr):
+            return (fr is not None and tuple(fr[0].shape) == (HEIGHT, WIDTH, 3) and bool(torch.equal(fr[0], ref_lin.to(fr[0].device)))
+                    and bool(torch.equal(fr[1], ref_rgba.to(fr[1].device))))
+        frame_ok = same(last_frame)
+        if not frame_ok:
+            problems.append("the last timed frame differs from the job rendered alone, in order, on one GPU")
+        if copy_run:
+            copy_run["frame_ok"] = same(copy_run["last"])
+            if not copy_run["frame_ok"]:
+                problems.append("exchange by copies: the last timed frame differs from the job rendered alone, in order, on one GPU")
+        del ref_lin, ref_rgba
+    if dist_path:
+        # every rank learns whether any rank found a problem (a rank must not leave the others waiting in a collective)
+        flag = torch.tensor([1.0 if problems else 0.0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() and not problems:
+            problems.append("another rank reported a problem")
+        if problems and rank != 0:
+            print(f"[bench rank {rank}] " + "; ".join(problems), file=sys.stderr, flush=True)
+
+    if rank == 0:
         # the dominant kernel = the level-0 launch of each batch (camera rays + every bounce until its waves hand
         # their sparse tails over); it processes p_vertices of the vertices and all of the camera samples.
         # Single-process multi-device runs: counters are sums over the devices, launch times the slowest device's
@@ -525,6 +591,12 @@ def main(argv=None):
                 "hit_scene": accel_name,
                 "samples_per_step": int(job_samples / args.steps),
                 "vertices_per_sample": round(acc["vertices"] / max(acc["samples"], 1), 3),
+                # the same figure from the device counters of the TIMED (overlapped) region, rank 0 / all devices of the process;
+                # `samples` there are counted on the device where a path's radiance is written (PtStats.samples)
+                "timed_region_vertices_per_sample": round(timed["vertices"] / max(timed["samples"], 1), 3),
+                "timed_region_samples": int(timed["samples"]),
+                "timed_region_counters_equal_steps_x_per_step": not any(p.startswith("timed region") for p in problems),
+                "frame_equals_single_gpu": bool(frame_ok),
                 "launch": {"single": "one process, one GPU", "multi": "one process, all GPUs (pt_multi_*)",
                            "dist": "one process per GPU (torch.distributed)"}[mode] +
                           (f" -- REHEARSAL: {world} contexts on ONE device, copies in place of ncclGather; not a measurement of {world} GPUs"
@@ -555,12 +627,23 @@ def main(argv=None):
             roof["launch_times_from"] = "HIP events around every path-kernel launch of the timed steps (--in-order: launches strictly one after the other)"
         if host_buffers:
             out["host_buffers"] = host_buffers
-        if world == 1 and not args.no_cpu_baseline:
+        if copy_run:
+            out["config"]["exchange_copy"] = {
+                "value": round(float(copy_run["timed"]["samples"]) / copy_run["elapsed"] / 1e6, 2), "unit": "Msamples/s",
+                "ms_per_step": round(copy_run["elapsed"] / args.steps * 1e3, 3), "frame_equals_single_gpu": bool(copy_run["frame_ok"]),
+                "what": "the same timed region with pt_multi_set_exchange(PT_EXCHANGE_COPY): one DMA copy per device in place of the "
+                        "ncclGather (no kernel takes part in the exchange); `value` above is the ncclGather form"}
+        if problems:
+            out["verification_failed"] = problems
+        if world == 1 and not args.no_cpu_baseline and not problems:
             out["cpu_baseline"] = cpu_baseline(pt, objs, WIDTH, HEIGHT, SPP, wl_desc.split(":")[0] + " scene")
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist_path:
         dist.destroy_process_group()
+    if problems:
+        print("bench.py: the record does not verify: " + "; ".join(problems), file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

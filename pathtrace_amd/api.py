@@ -118,6 +118,10 @@ class Context:
         check(lib().pt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(linear_ptr),
                                      C.c_void_p(rgba_ptr) if rgba_ptr else None))
 
+    def fail_after(self, n):
+        """Test hook (pt_debug_fail_after): the n-th stream operation of the NEXT render fails as a HIP call would; n < 0: none."""
+        check(lib().pt_debug_fail_after(self._h, int(n)))
+
     def scan_layout(self):
         """-> (spheres, single triangles, triangle pairs) one linear scan of the uploaded scene tests (pt_debug_scan_layout)"""
         a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)

@@ -548,6 +548,12 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
     HIP_TRY(hipStreamSynchronize(c->stream));   // the previous scene may still be in use
     ptsched::on_scene(c->sched);                 // statistics of renders of the previous scene do not carry over
     c->expected_samples = 0;
+    // (the statistics words are zero whenever no render is pending; on the context's stream, which is idle here: a plain hipMemset
+    // runs on the legacy default stream, which a non-blocking stream does not wait for)
+    if (c->ovf_count.p && hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), c->stream) == hipSuccess &&
+        hipStreamSynchronize(c->stream) == hipSuccess)
+        c->sched.stats_clean = 1;
+    c->capture_gcd = 0;                          // (graphs captured over the previous scene must not be replayed any more: its buffers are gone)
     std::memset(c->regen_occ, 0, sizeof c->regen_occ);
     if (!scan.empty()) HIP_TRY(hipMemcpy(c->scan.p, scan.data(), scan.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->shape.p, shape.data(), shape.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -650,6 +656,9 @@ void sched_recover(PtContext* c, hipStream_t st, const ptsched::State& planned) 
     (void)hipGetLastError();
     ptsched::on_failure(c->sched, planned);
     c->expected_samples = 0;
+    if (c->ovf_count.p && hipMemsetAsync(c->ovf_count.p, 0, kStatsWords * sizeof(uint32_t), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+        c->sched.stats_clean = 1;
+    (void)hipGetLastError();
 }
 
 // The render driver behind every rendering entry: everything src/main.rs:43-60 does for the tile (or, with `list`,
@@ -820,7 +829,15 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
     if (overlap && hand_off && prm->accel && ((rc = c->caux.ensure(q_slots_cont)) || (rc = c->csray[0].ensure(q_slots_cont)) ||
                                               (rc = c->csray[1].ensure(q_slots_cont))))
         return rc;
-    if ((rc = c->ovf_count.ensure(kStatsWords + kSets * kCountStride))) return rc;   // [render statistics | launch counters of buffer set 0 | 1 | ...]
+    if (!c->ovf_count.p) {             // [render statistics | launch counters of buffer set 0 | 1 | ...], zero from the start
+        if ((rc = c->ovf_count.ensure(kStatsWords + kSets * kCountStride))) return rc;
+        // (on the caller's stream and waited for: a plain hipMemset runs on the legacy default stream, which the context's
+        // non-blocking streams do not wait for -- the first render's counts raced with it, caught by pt_sync's own sample check)
+        HIP_TRY(hipMemsetAsync(c->ovf_count.p, 0, (kStatsWords + kSets * kCountStride) * sizeof(uint32_t), st));
+        HIP_TRY(hipStreamSynchronize(st));
+        c->sched.stats_clean = 1;
+        for (int k = 0; k < kSets; ++k) c->sched.counters_clean[k] = 1;
+    }
     if (hand_off)
         for (int par = 0; par < (overlap ? 2 : 1); ++par)
             for (int k = 0; k < 4; ++k)
@@ -858,7 +875,10 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
 
     // ---- PLAN (pure; on a copy of the state)
     ptsched::State next = c->sched;
-    const ptsched::Plan plan = ptsched::plan(next, job);
+#ifndef PT_SCHED_FAULTS
+#define PT_SCHED_FAULTS 0        // measurement / demonstration builds only: ptsched::Faults switched on in the product path
+#endif
+    const ptsched::Plan plan = ptsched::plan(next, job, PT_SCHED_FAULTS);
     if (plan.profile) {
         uint32_t top = 0;
         for (const ptsched::Op& o : plan.ops) if (o.kind == ptsched::kOpRecord && o.event == ptsched::kEvPool) top = std::max(top, o.pool + 1u);
@@ -977,6 +997,8 @@ int render_impl(PtContext* c, const PtCamera* cam, const PtRenderParams* prm, co
             return rc;
         }
 
+    c->debug_fail_at = -1;              // (the hook is for ONE render)
+
     // ---- COMMIT
     if (!plan.accumulate) begin_period();
     c->sched = next;
@@ -1053,6 +1075,9 @@ int pt_sync(PtContext* c) {
         c->stats.samples_expected = exp;
         bool ok = dev == exp;
         if (!ok && c->capture_gcd) ok = dev >= exp && (dev - exp) % c->capture_gcd == 0;
+#if defined(PT_COUNT_FINISHED) && !PT_COUNT_FINISHED
+        ok = true;                        // measurement build whose kernels do not count (A/B of the counting's cost only)
+#endif
         c->expected_samples = 0;
         if (c->h_dstats[7] != 0)     // a kernel found one of its own invariants violated: the film is not to be trusted
             rc = fail(PT_ERR_HIP, "internal: the exchange stacks of k_paths_regen_split overflowed (please report; PtTuning.level0_form = 1 avoids the kernel)");

@@ -155,12 +155,8 @@ constexpr uint32_t kBvhStack = PT_BVH_STACK;         // traversal stack entries 
 #define PT_REGEN_WAVES_SPLIT 5
 #endif
 constexpr uint32_t kRegenWavesDiffuse = PT_REGEN_WAVES_DIFFUSE, kRegenWavesGeneric = 5, kRegenWavesSplit = PT_REGEN_WAVES_SPLIT;
-// k_paths_regen_split: float4 of exchange memory per wave of the launch: 128 stack entries of 5 float4 (round 3 also kept 64
-// parking slots of 4 here; the plain paths are parked in LDS now, PT_SPLIT_PARK_LDS)
-#ifndef PT_SPLIT_PARK_LDS
-#define PT_SPLIT_PARK_LDS 1
-#endif
-constexpr uint32_t kRegenSplitF4PerWave = 128u * 5u + (PT_SPLIT_PARK_LDS ? 0u : 64u * 4u);
+// k_paths_regen_split: float4 of exchange memory per wave of the launch: 128 stack entries of 5 float4
+constexpr uint32_t kRegenSplitF4PerWave = 128u * 5u;
 // chunk counters of k_paths_regen: chunk_counter[c * kRegenCounterStride], c < kRegenCounters (256 bytes apart)
 constexpr uint32_t kRegenCounters = 8, kRegenCounterStride = 64;
 // pt_scene_upload: per-object constants written into the shape / material records (k_scene_setup), one call per arithmetic

@@ -342,6 +342,40 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
     return q * t.band_stride + t.band_first + (yl - q * t.band_rows);
 }
 
+// End of a wave: its statistics go to the launch's totals.  Every wave adding them to the same five global words itself is
+// ~30 000 atomics on ONE cache line per launch, serialised in L2 at the very end of the launch, where every microsecond is tail
+// (measured: the fifth word, the finished-sample count, alone cost 1.5 % of a C2 launch: profiles/r05/ab_count_finished.txt).
+// So the waves of a workgroup add up in LDS first and the LAST of them to end does the global atomics: a quarter of the traffic.
+#ifndef PT_WG_TOTALS
+#define PT_WG_TOTALS 1
+#endif
+struct WgTotals { uint32_t done, shadow, vertices, samples, dmax; };
+PT_DEV void wg_totals_init(WgTotals& t) {                 // by one thread, before the workgroup's first barrier
+    t.done = 0u; t.shadow = 0u; t.vertices = 0u; t.samples = 0u; t.dmax = 0u;
+}
+// called by lane 0 of every wave that ran (spare workgroups that end at once never get here); waves_in_block of them
+template <bool MIS, bool PRIMARY = true>     // PRIMARY: a level-0 launch (its vertices also count as primary_vertices)
+PT_DEV void wave_totals(WgTotals& t, uint32_t waves_in_block, unsigned long long* stats, uint32_t shadow, uint32_t vertices,
+                        uint32_t samples, uint32_t dmax) {
+#if PT_WG_TOTALS
+    if (MIS && shadow != 0u) __hip_atomic_fetch_add(&t.shadow, shadow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (vertices != 0u) __hip_atomic_fetch_add(&t.vertices, vertices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (samples != 0u) __hip_atomic_fetch_add(&t.samples, samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (vertices != 0u) __hip_atomic_fetch_max(&t.dmax, dmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (acq_rel: the sums of the waves that ended earlier are visible to the one that finds itself last)
+    if (__hip_atomic_fetch_add(&t.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u != waves_in_block) return;
+    shadow = __hip_atomic_load(&t.shadow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    vertices = __hip_atomic_load(&t.vertices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    samples = __hip_atomic_load(&t.samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    dmax = __hip_atomic_load(&t.dmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    if (MIS && shadow != 0u) atomicAdd(&stats[0], (unsigned long long)shadow);
+    if (vertices != 0u) atomicAdd(&stats[1], (unsigned long long)vertices);
+    if (PRIMARY && vertices != 0u) atomicAdd(&stats[3], (unsigned long long)vertices);
+    if (vertices != 0u) atomicMax(&stats[2], (unsigned long long)dmax);
+    if (samples != 0u) atomicAdd(&stats[4], (unsigned long long)samples);
+}
+
 // ------------------------------------------------------------------ one path vertex
 // The per-vertex body of MisStrategy::ray_color / BrdfOnlyStrategy::ray_color (rendering.rs:34-142,
 // 214-265), cut at the visibility scan: vertex_begin (hit record, emitter credit, light sample) -> shadow
@@ -405,8 +439,13 @@ PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_
     uint32_t dc[4];
     philox4x32_draw(px, py, sample, kDepthCamera, BLK_SURFACE, 0u, dc);
     float ox = u01(dc[0]), oy = u01(dc[1]);                               // world.rs:299 (ox first)
-    float u = pt_div((float)px + ox, (float)(cam.width - 1u));               // camera.rs:140
-    float v = pt_div((float)(cam.height - 1u - py) + oy, (float)(cam.height - 1u));   // world.rs:299 y flip
+    // (The divisors go through an empty asm: the compiler otherwise hoists their reciprocals out of the path loop of the
+    // regenerating kernels into two registers that live -- or are spilled -- for the whole kernel; camera rays are generated once
+    // per 64-path chunk, two reciprocals there cost nothing.  Same arithmetic.)
+    float wm1 = (float)(cam.width - 1u), hm1 = (float)(cam.height - 1u);
+    asm volatile("" : "+v"(wm1), "+v"(hm1));
+    float u = pt_div((float)px + ox, wm1);                                   // camera.rs:140
+    float v = pt_div((float)(cam.height - 1u - py) + oy, hm1);               // world.rs:299 y flip
     const f3 cam_o = mk(cam.origin[0], cam.origin[1], cam.origin[2]);
     f3 dir = mk(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]) +
              mk(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]) * u +
@@ -620,8 +659,13 @@ PT_DEV void launch_shape(const BounceArgs& a, uint32_t nw, uint32_t& n_first, ui
         seg_cap = ((((n_first + 63u) >> 6) + nw - 1u) / nw) * 64u;
     }
 }
+// ... and the generic-material instances of the LDS form (GGX + OrenNayar code in the kernel): what pixel lists, pt_ray_color and
+// batches of <= 2^17 paths take on the reference's own scene.  At 6 waves (80 VGPRs) they spill 14-18 registers.
+#ifndef PT_BOUNCE_WAVES_LDS_GENERIC
+#define PT_BOUNCE_WAVES_LDS_GENERIC 5      // round 5: 93-95 VGPRs, no spills; small jobs on World::new() 6-9 % faster than at 6 waves (profiles/r05/ab_generic_waves.txt)
+#endif
 template <int MODE, bool MIS, bool OVF, bool DIFFUSE, bool LIST>   // OVF: continuation launch, pass 0 reads the overflow queue
-__global__ void __launch_bounds__(kBlock, MODE == kModeLds ? PT_BOUNCE_WAVES_LDS : PT_BOUNCE_WAVES_TILED)
+__global__ void __launch_bounds__(kBlock, MODE == kModeLds ? (DIFFUSE ? PT_BOUNCE_WAVES_LDS : PT_BOUNCE_WAVES_LDS_GENERIC) : PT_BOUNCE_WAVES_TILED)
 k_paths(BounceArgs a) {
     // SMALL = "the waves of a workgroup are independent" (no barrier inside the scan): wave-private queue
     // segments.  The tiled scan ties the four waves of a workgroup together.  (kModeBvh: k_paths_bvh.)
@@ -629,6 +673,9 @@ k_paths(BounceArgs a) {
     constexpr bool SMALL = MODE == kModeLds;
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_iters[kBlock / 64];
+    __shared__ WgTotals s_totals;
+    if (threadIdx.x == 0u) wg_totals_init(s_totals);
+    if (MODE != kModeLds) __syncthreads();      // (kModeLds: stage_scene's barrier publishes it)
     const SceneRef sc = stage_scene<MODE>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -788,14 +835,8 @@ k_paths(BounceArgs a) {
             for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + threadIdx.x]; a.ovf_out.q[k][base + threadIdx.x] = t; }
         }
     }
-    if (lane == 0u) {
-        // totals for the host: shadow rays, vertices (= loop iterations summed over paths), deepest vertex
-        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
-        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
-        if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);   // level-0 launches only
-        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
-        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
-    }
+    // totals for the host: shadow rays, vertices (= loop iterations summed over paths), deepest vertex, finished samples
+    if (lane == 0u) wave_totals<MIS, !OVF>(s_totals, kBlock / 64, a.stats, wave_shadow, wave_vertices, wave_samples, wave_depth);
 }
 
 // ------------------------------------------------------------------ the path kernel, regenerating form
@@ -822,27 +863,15 @@ k_paths(BounceArgs a) {
 //     sample has its own slot of lsamp, and the statistics are sums.
 // Occupancy the variants are compiled for (pt_kernels.h: the host sizes the grid by it): the DIFFUSE variant needs 79 VGPRs
 // (6 waves per SIMD), the generic one 93 (5; reached only with PtTuning.level0_form = 2).
-// Finished samples are counted where their radiance is written (stats[4]; pt_sync compares the sum with pixels x spp).  The
-// regenerating kernels have no scalar register left for one more wave-uniform counter (106 of 106 SGPRs: it would cost the
-// split form two more spilled VGPRs), so a lane keeps its count in the high half of the word that holds the deepest vertex
-// of the paths it finished (depth < 65535, vertex_end).  A lane cannot finish more paths than enter its wave, 64 per ring
-// refill, so the refill loop is where the count is checked for overflow (fin_flush_if_full).
-PT_DEV void note_finished(uint32_t& fin, uint32_t depth) {
-    const uint32_t d = fin & 0xFFFFu;
-    fin = (fin & 0xFFFF0000u) + 0x10000u + (depth > d ? depth : d);
-}
-PT_DEV void fin_flush_if_full(uint32_t& fin, unsigned long long* stats) {
-    if (fin >= 0x80000000u) { atomicAdd(&stats[4], (unsigned long long)(fin >> 16)); fin &= 0xFFFFu; }
-}
-// end of the wave: lane 0 gets (sum of the lanes' counts, max of their depths)
-PT_DEV void fin_reduce(uint32_t fin, uint32_t& count, uint32_t& dmax) {
-    count = fin >> 16; dmax = fin & 0xFFFFu;
-    for (int off = 32; off > 0; off >>= 1) {
-        count += (uint32_t)__shfl_xor((int)count, off);
-        const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off);
-        dmax = w2 > dmax ? w2 : dmax;
-    }
-}
+// Finished samples (stats[4]; pt_sync compares the sum with pixels x spp).  The queue-form kernels count the lanes that write their
+// radiance to the sample buffer (a ballot at the store).  In the regenerating kernels a lane's ONLY transition from "has a path" to
+// "has none" is that store, and paths enter a wave only from its ring, so finished = (entries taken from the ring) - (paths handed
+// over at the end): one scalar add per iteration on a number the loop computes anyway.  (Counting at the store itself was measured:
+// a per-lane count packed into the depth word cost 1.5 % on C2 -- profiles/r05/ab_count_finished.txt; a ballot per iteration
+// costs the split form two more spilled registers.)
+#ifndef PT_COUNT_FINISHED
+#define PT_COUNT_FINISHED 1      // 0: measurement variant without the count (pt_sync's check is compiled out with it: A/B of its cost only)
+#endif
 constexpr uint32_t kPool = 128;            // ring entries per wave (>= 2 chunks: refilled whenever fewer than 64 are left)
 // Workgroup size of k_paths_regen.  Its waves share nothing but the LDS copy of the scene, so a workgroup could be ONE wave --
 // a wave that ends would free a slot the next launch (pt_api.cpp, lanes) can take at once, where a four-wave workgroup needs
@@ -874,6 +903,8 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
     extern __shared__ float4 lds[];
     __shared__ float4 s_pool_d[kRegenBlock / 64][kPool];      // (d.x, d.y, d.z, bits(tile_row << 16 | x))
     __shared__ uint32_t s_pool_s[kRegenBlock / 64][kPool];    // s_local << 16 (depth 0)
+    __shared__ WgTotals s_totals;
+    if (threadIdx.x == 0u) wg_totals_init(s_totals);
 #if PT_DRAIN_MAIL
     // End of the batch: a wave left with a handful of paths hands them to a sibling wave of its workgroup and ends (see the
     // main loop).  One region per donor wave, plane-major; cnt = entries published, head = entries taken (atomic), active =
@@ -909,7 +940,8 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
     uint32_t pool_head = 0, pool_cnt = 0;  // wave-uniform: ring read position, entries
     bool exhausted = false;                // wave-uniform: the batch has no more chunks
     uint32_t wave_shadow = 0, wave_vertices = 0;
-    uint32_t fin = 0;                      // per lane: paths this lane finished << 16 | their deepest vertex (note_finished)
+    uint32_t wave_taken = 0;               // wave-uniform: paths this wave's lanes took from the ring (finished = taken - handed over)
+    uint32_t dmax = 0;                     // per lane: deepest vertex of the paths this lane finished
     PathState p = parked_state();
     bool alive = false;
 #if PT_DRAIN_MAIL
@@ -962,7 +994,6 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
                 pool_s[e] = s_local << 16;
             }
             pool_cnt += valid;
-            fin_flush_if_full(fin, a.stats);
         }
         __builtin_amdgcn_wave_barrier();
 #if PT_DRAIN_PRIO == 1
@@ -997,6 +1028,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
             const uint32_t n_need = (uint32_t)__popcll(need);
             const uint32_t n_take = n_need < pool_cnt ? n_need : pool_cnt;
             pool_head += n_take; pool_cnt -= n_take;
+            if (PT_COUNT_FINISHED) wave_taken += n_take;
         }
         __builtin_amdgcn_wave_barrier();
 #if PT_DRAIN_MAIL
@@ -1102,7 +1134,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
         alive = vertex_end<MIS, DIFFUSE, true>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
         if (active && !alive) {
             a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
-            note_finished(fin, p.depth);
+            dmax = p.depth > dmax ? p.depth : dmax;
             p.o = parked_origin(); p.d = parked_dir();  // until the lane gets its next path (end of the batch: for good)
         }
     }
@@ -1118,19 +1150,15 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
             if (alive) {
                 store_state(a.ovf_out, base + lane_rank(mask), p);
                 const uint32_t done = p.depth ? p.depth - 1u : 0u;   // deepest vertex it has been through (0: none yet)
-                const uint32_t d = fin & 0xFFFFu;
-                fin = (fin & 0xFFFF0000u) | (done > d ? done : d);
+                dmax = done > dmax ? done : dmax;
             }
         }
+        wave_taken -= n_left;              // (mail pooling, a measurement variant, moves paths between waves: the launch's sum stays right)
     }
-    uint32_t wave_samples, dmax;
-    fin_reduce(fin, wave_samples, dmax);
+    const uint32_t wave_samples = wave_taken;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off); dmax = w2 > dmax ? w2 : dmax; }
     if (lane == 0u) {
-        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
-        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
-        if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
-        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
-        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
+        wave_totals<MIS>(s_totals, kRegenBlock / 64, a.stats, wave_shadow, wave_vertices, wave_samples, dmax);
 #ifdef PT_DRAIN_TIMING      // stats[8..12] (beyond the 8 words the host reads): ~begin (min), ~exhausted (min), exhausted (max), end (max), sum of per-wave drain times
         const unsigned long long t_end = wall_clock64();
         if (t_exhausted == 0ull) t_exhausted = t_end;
@@ -1168,14 +1196,20 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
 constexpr int kWaitVm0 = 0x0F70;                                 // s_waitcnt vmcnt(0) alone (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 constexpr uint32_t kXq = 128;                                    // exchange entries per wave
 constexpr uint32_t kXqEntryF4 = 5;                               // stack entry: 4 float4 of path state (layout of Queue) + (bits(id), t, -, -)
-constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4 + (PT_SPLIT_PARK_LDS ? 0u : 64u * 4u);   // the stacks (+ 64 parking slots of 4 float4 in the round-3 form)
+constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4;               // the stacks (round 3 also parked the wave's 64 plain paths here: LDS since round 4, ab_c1_park_in_lds.txt)
+#ifndef PT_SPLIT_STAY
+#define PT_SPLIT_STAY 0          // measured (round 5): 7.52 -> 7.62 ms per C1 launch at every threshold tried -- profiles/r05/ab_c1_stay_in_lane.txt
+#endif
+#ifndef PT_SPLIT_STAY_MIN
+#define PT_SPLIT_STAY_MIN 32
+#endif
+constexpr uint32_t kSplitStayMin = PT_SPLIT_STAY_MIN;             // a batch goes on while at least this many specials are in lanes + waiting
 static_assert(kXqF4PerWave == kRegenSplitF4PerWave, "pt_kernels.h sizes the buffer");
 // One wave-uniform base pointer (two scalar registers); entry-major, so the planes of an entry are immediate offsets of
 // ONE address -- with plane-major arrays the compiler kept a scalar base per plane (24 SGPRs more than the kernel has).
 struct XWave {
     float4* b;
     PT_DEV float4* entry(uint32_t e) const { return b + e * kXqEntryF4; }                  // [0..3] state, [4] = (bits(id), t, -, -) of a special entry's pending vertex
-    PT_DEV float4* park(uint32_t l) const { return b + kXq * kXqEntryF4 + l * 4u; }        // the wave's 64 plain paths while a batch of specials runs
 };
 PT_DEV XWave xwave(float4* base, uint32_t wave_uniform) {
     XWave x;
@@ -1197,7 +1231,9 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     extern __shared__ float4 lds[];
     __shared__ float4 s_pool_d[kBlock / 64][kPool];
     __shared__ uint32_t s_pool_s[kBlock / 64][kPool];
-    __shared__ float4 s_stage[kBlock / 64][4][64];       // a batch's survivors while the scan of their next vertex decides their stack (plane-major: conflict-free)
+    __shared__ float4 s_stage[kBlock / 64][4][64];       // the parking area of each wave's plain paths during a batch of specials (plane-major: conflict-free)
+    __shared__ WgTotals s_totals;
+    if (threadIdx.x == 0u) wg_totals_init(s_totals);
     if (a.posted != nullptr && blockIdx.x >= a.core_blocks) {       // spare workgroup (see k_paths_regen)
         __shared__ uint32_t s_posted;
         if (threadIdx.x == 0u) s_posted = __hip_atomic_load(a.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1209,11 +1245,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     const uint32_t wib = threadIdx.x >> 6;
     float4* const pool_d = s_pool_d[wib];
     uint32_t* const pool_s = s_pool_s[wib];
-#if PT_SPLIT_PARK_LDS
     float4 (*const park)[64] = s_stage[wib];             // the wave's plain paths while a batch of specials runs
-#else
-    float4 (*const stage)[64] = s_stage[wib];
-#endif
     const uint32_t n_first = a.n_first;
     const uint32_t n_chunks = (n_first + 63u) >> 6;
     const uint32_t W = a.film_w;
@@ -1228,7 +1260,8 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
     uint32_t sq_cnt = 0, pq_cnt = 0;       // wave-uniform: special entries [0, sq_cnt), plain entries [kXq - pq_cnt, kXq)
     bool overflow = false;                 // wave-uniform: the stacks met (cannot happen, see above; reported instead of corrupting paths)
     uint32_t wave_shadow = 0, wave_vertices = 0;
-    uint32_t fin = 0;                      // per lane: paths finished << 16 | their deepest vertex (note_finished)
+    uint32_t wave_taken = 0;               // wave-uniform: paths taken from the ring; every one of them ends in this wave (no hand-over)
+    uint32_t dmax = 0;
     PathState p = parked_state();
     bool alive = false;
 
@@ -1262,7 +1295,6 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 pool_s[e] = s_local << 16;
             }
             pool_cnt += valid;
-            fin_flush_if_full(fin, a.stats);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- lanes without a path: first the plain stack (paths that left a Mirror surface), then the ring
@@ -1296,6 +1328,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
             pq_cnt -= n_pq;
             const uint32_t n_ring = n_need - n_pq < pool_cnt ? n_need - n_pq : pool_cnt;
             pool_head += n_ring; pool_cnt -= n_ring;
+            if (PT_COUNT_FINISHED) wave_taken += n_ring;
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
@@ -1313,7 +1346,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 if (special) {
                     float4* dst = x.entry(sq_cnt + lane_rank(spm));
                     store_entry(dst, p);
-                    dst[4] = make_float4(__int_as_float(id), t, 0.0f, 0.0f);
+                    *reinterpret_cast<float2*>(dst + 4) = make_float2(__int_as_float(id), t);     // (8 of the slot's 16 bytes: no padding words to keep in registers)
                     alive = false;
                     p.o = parked_origin(); p.d = parked_dir();
                     id = -1;
@@ -1342,7 +1375,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
             alive = vertex_end<MIS, PLAIN, true>(sc, p, v, visible, sample, kx, py, a.min_depth, a.max_depth);
             if (active && !alive) {
                 a.lsamp[p.s_local * a.np + p.yl * W + p.px] = Rgb{p.L.x, p.L.y, p.L.z};
-                note_finished(fin, p.depth);
+                dmax = p.depth > dmax ? p.depth : dmax;
                 p.o = parked_origin(); p.d = parked_dir();
             }
         }
@@ -1350,24 +1383,90 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
         // ---- batches of Mirror vertices: whenever a full wave of them waits, or nothing else is left to do
         auto plain_work = [&]() { return __ballot(alive) != 0ull || pool_cnt != 0u || !exhausted || pq_cnt != 0u; };
         if (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work())) {
-#if PT_SPLIT_PARK_LDS
             // park the plain paths in LDS for the batch (round 4): their 16 registers carry the batch's paths instead -- the
             // popped entry WHOLE (one wait per batch iteration instead of one for the ray part and one for the carry part), and
-            // the survivors across the scan of their next vertex (round 3 staged them in these LDS slots and parked the plain
-            // paths in global memory: 8 KB of stack traffic and three exposed round trips per batch more)
+            // the survivors across the scan of their next vertex
             park[0][lane] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
             park[1][lane] = make_float4(p.d.y, p.d.z, __uint_as_float((p.yl << 16) | p.px), __uint_as_float((p.s_local << 16) | p.depth));
             park[2][lane] = make_float4(p.beta.x, p.beta.y, p.beta.z, p.pdf_prev);
             park[3][lane] = make_float4(p.L.x, p.L.y, p.L.z, p.eta_in);
-#else
-            // park the plain paths: their 16 registers are free during the batch.  (The lane index goes through an empty
-            // asm so that the compiler computes the parking / staging addresses here instead of hoisting twelve 64-bit
-            // address pairs out of the path loop into registers it then has to spill.)
-            uint32_t ln = lane;
-            asm volatile("" : "+v"(ln));
-            store_entry(x.park(ln), p);
-#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // entries pushed above are read by other lanes below
+#if PT_SPLIT_STAY
+            // Round 5: a path whose NEXT vertex is Mirror again (it is inside the glass sphere: most of what a batch refracts)
+            // STAYS in its lane with the scan's (id, t) and is shaded by the next iteration of this loop, where the lanes the
+            // others freed take what still waits on the stack.  Round 4 pushed it (80 B written) and popped it again in a later
+            // batch (80 B read): a third of the form's stack traffic, and a dozen plain iterations of latency for the path.
+            PathState q = parked_state();
+            bool qa = false;                                           // this lane carries a special waiting for its vertex
+            int qid = -1; float qt = 0.0f;
+            uint32_t n_stay = 0;                                       // wave-uniform: lanes with qa
+            do {
+                {   // lanes without a special take the top entries of the special stack, in lane order
+                    const unsigned long long need = __ballot(!qa);
+                    const uint32_t r = lane_rank(need);
+                    const uint32_t n_need = (uint32_t)__popcll(need);
+                    const uint32_t n_pop = n_need < sq_cnt ? n_need : sq_cnt;
+                    if (!qa && r < n_pop) {
+                        const float4* src = x.entry(sq_cnt - 1u - r);
+                        q = unpack_state(src[0], src[1], src[2], src[3]);
+                        const float2 it = *reinterpret_cast<const float2*>(src + 4);
+                        qid = __float_as_int(it.x); qt = it.y;
+                        qa = true;
+                    }
+                    sq_cnt -= n_pop;
+                    n_stay += n_pop;
+                }
+                if (!qa) { q.o = parked_origin(); q.d = parked_dir(); qid = -1; }
+                const uint32_t kx = q.px, py = image_row(a.tile, q.yl);
+                const uint32_t sample = a.s_base + q.s_local;
+                wave_vertices += n_stay;
+                Vertex v;
+                vertex_begin<MIS, kMatsAll>(sc, q, qa, qid, qt, sample, kx, py, v);
+                bool visible = false;
+                if (MIS) {
+                    const unsigned long long sm = __ballot(v.need_shadow);
+                    if (sm != 0ull) {
+                        f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
+                        f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
+                        int sid; float st;
+                        scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                        visible = v.need_shadow && sid < 0;
+                        wave_shadow += (uint32_t)__popcll(sm);
+                    }
+                }
+                const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
+                if (qa && !qalive) {
+                    a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
+                    dmax = q.depth > dmax ? q.depth : dmax;
+                }
+                // the survivors' next vertex: Mirror again or not?
+                const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
+                asm volatile("" ::: "memory");
+                int id2; float t2;
+                scan_closest<kModeLds>(sc, so, sd, a.t_min, kInf, id2, t2);
+                const bool spec2 = qalive && id2 >= 0 && is_mirror_obj(sc, id2);
+                const bool plain2 = qalive && !spec2;
+                const unsigned long long m_p = __ballot(plain2);
+                const uint32_t n_p = (uint32_t)__popcll(m_p);
+                if (plain2) store_entry(x.entry(kXq - pq_cnt - n_p + lane_rank(m_p)), q);
+                pq_cnt += n_p;
+                qa = spec2; qid = id2; qt = t2;
+                n_stay = (uint32_t)__popcll(__ballot(spec2));
+                overflow = overflow || sq_cnt + pq_cnt + n_stay > kXq;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            } while (n_stay + sq_cnt >= kSplitStayMin || (n_stay + sq_cnt != 0u && !plain_work()));
+            // what stays below the threshold waits on the special stack for the next batch, like a special a plain iteration found
+            if (n_stay != 0u) {
+                const unsigned long long m_s = __ballot(qa);
+                if (qa) {
+                    float4* de = x.entry(sq_cnt + lane_rank(m_s));
+                    store_entry(de, q);
+                    *reinterpret_cast<float2*>(de + 4) = make_float2(__int_as_float(qid), qt);
+                }
+                sq_cnt += n_stay;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+#else
             do {
                 const uint32_t n = sq_cnt < 64u ? sq_cnt : 64u;
                 const bool qa = lane < n;
@@ -1376,12 +1475,8 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 int qid = -1; float qt = 0.0f;
                 if (qa) {
                     const float4* src = x.entry(e);
-#if PT_SPLIT_PARK_LDS
                     q = unpack_state(src[0], src[1], src[2], src[3]);
-#else
-                    unpack_ray(q, src[0], src[1]);
-#endif
-                    const float4 it = src[4];
+                    const float2 it = *reinterpret_cast<const float2*>(src + 4);
                     qid = __float_as_int(it.x); qt = it.y;
                 }
                 sq_cnt -= n;
@@ -1402,26 +1497,12 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                         wave_shadow += (uint32_t)__popcll(sm);
                     }
                 }
-#if !PT_SPLIT_PARK_LDS
-                // the carry part only now (as k_paths does): eight registers less during the scans
-                asm volatile("" ::: "memory");
-                if (qa) { const float4* src = x.entry(e); unpack_carry(q, src[2], src[3]); }
-#endif
                 const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
                 if (qa && !qalive) {
                     a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
-                    note_finished(fin, q.depth);
+                    dmax = q.depth > dmax ? q.depth : dmax;
                 }
                 // the survivors' next vertex: Mirror again (a path inside the sphere) or not?
-#if !PT_SPLIT_PARK_LDS
-                // Their state waits in the staging slots meanwhile; the scan needs the ray only.
-                if (qalive) {
-                    stage[0][lane] = make_float4(q.o.x, q.o.y, q.o.z, q.d.x);
-                    stage[1][lane] = make_float4(q.d.y, q.d.z, __uint_as_float((q.yl << 16) | q.px), __uint_as_float((q.s_local << 16) | q.depth));
-                    stage[2][lane] = make_float4(q.beta.x, q.beta.y, q.beta.z, q.pdf_prev);
-                    stage[3][lane] = make_float4(q.L.x, q.L.y, q.L.z, q.eta_in);
-                }
-#endif
                 const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
                 asm volatile("" ::: "memory");
                 int id2; float t2;
@@ -1433,37 +1514,23 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 if (qalive) {
                     const uint32_t dst = spec2 ? sq_cnt + lane_rank(m_s) : kXq - pq_cnt - n_p + lane_rank(m_p);
                     float4* de = x.entry(dst);
-#if PT_SPLIT_PARK_LDS
                     store_entry(de, q);
-#else
-                    const float4 s0 = stage[0][lane], s1 = stage[1][lane], s2 = stage[2][lane], s3 = stage[3][lane];
-                    de[0] = s0; de[1] = s1; de[2] = s2; de[3] = s3;
-#endif
-                    if (spec2) de[4] = make_float4(__int_as_float(id2), t2, 0.0f, 0.0f);
+                    if (spec2) *reinterpret_cast<float2*>(de + 4) = make_float2(__int_as_float(id2), t2);
                 }
                 sq_cnt += (uint32_t)__popcll(m_s);
                 pq_cnt += n_p;
                 overflow = overflow || sq_cnt + pq_cnt > kXq;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             } while (sq_cnt >= 64u || (sq_cnt != 0u && !plain_work()));
-#if PT_SPLIT_PARK_LDS
-            p = unpack_state(park[0][lane], park[1][lane], park[2][lane], park[3][lane]);
-#else
-            asm volatile("" : "+v"(ln));
-            { const float4* pk = x.park(ln); p = unpack_state(pk[0], pk[1], pk[2], pk[3]); }
-            __builtin_amdgcn_s_waitcnt(kWaitVm0);      // as above: no pending load may leave this branch
 #endif
+            p = unpack_state(park[0][lane], park[1][lane], park[2][lane], park[3][lane]);
         }
     }
 
-    uint32_t wave_samples, dmax;
-    fin_reduce(fin, wave_samples, dmax);
+    const uint32_t wave_samples = wave_taken;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t w2 = (uint32_t)__shfl_xor((int)dmax, off); dmax = w2 > dmax ? w2 : dmax; }
     if (lane == 0u) {
-        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
-        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
-        if (wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
-        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)dmax);
-        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
+        wave_totals<MIS>(s_totals, kBlock / 64, a.stats, wave_shadow, wave_vertices, wave_samples, dmax);
         if (overflow) atomicMax(&a.stats[7], 1ull);      // pt_sync turns it into an error
     }
 }
@@ -1715,6 +1782,9 @@ template <bool MIS, bool OVF, bool DIFFUSE, bool LIST>
 __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a) {
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_hist[kBlock / 64][64];                 // sort_segment: bucket counters of each wave
+    __shared__ WgTotals s_totals;
+    if (threadIdx.x == 0u) wg_totals_init(s_totals);
+    __syncthreads();                                             // (the traversal form has no barrier of its own before a wave can end)
     const SceneRef sc = stage_scene<kModeBvh>(a.sc, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -1831,13 +1901,7 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
             for (int k = 0; k < 4; ++k) { const float4 t = a.q.q[k][seg_base + j]; a.ovf_out.q[k][base + j] = t; }
         }
     }
-    if (lane == 0u) {
-        if (MIS && wave_shadow != 0u) atomicAdd(&a.stats[0], (unsigned long long)wave_shadow);
-        if (wave_vertices != 0u) atomicAdd(&a.stats[1], (unsigned long long)wave_vertices);
-        if (!OVF && wave_vertices != 0u) atomicAdd(&a.stats[3], (unsigned long long)wave_vertices);
-        if (wave_vertices != 0u) atomicMax(&a.stats[2], (unsigned long long)wave_depth);
-        if (wave_samples != 0u) atomicAdd(&a.stats[4], (unsigned long long)wave_samples);
-    }
+    if (lane == 0u) wave_totals<MIS, !OVF>(s_totals, kBlock / 64, a.stats, wave_shadow, wave_vertices, wave_samples, wave_depth);
 }
 
 static int scene_mode(const SceneView& sc, uint32_t accel) {

@@ -142,6 +142,8 @@ struct Job {
 enum : uint32_t {
     kFaultXchgStridePerRender = 1u,      // 514c507^: a lane's exchange region at lane * (this render's need) -- regions of renders with different grids overlap
     kFaultNoWaitAfterStreamWork = 2u,    // 41d6318^: a lanes render does not wait for a queue-form render still queued on the caller's stream
+    kFaultResolveBeforeLaunch = 4u,      // a resolve does not wait for its lane's launch (a deliberately broken build: -DPT_SCHED_FAULTS=4
+                                         // must make bench.py exit non-zero, profiles/r05/broken_build_is_caught.txt)
 };
 
 struct Plan {
@@ -212,11 +214,15 @@ inline Plan plan(State& s, const Job& j, uint32_t faults = 0) {
     }
 
     // The device-side words are normally zero already.  Only a fresh buffer, a new scene or a render that failed half-way leaves
-    // something to clear here -- and a CAPTURED render always clears what it uses itself (nothing executes during the capture, so
-    // the flags say nothing about the moment of a replay) and leaves the flags alone.
+    // something to clear here -- and a CAPTURED render always clears the launch counters it uses itself (nothing executes during the
+    // capture, so the flags say nothing about the moment of a replay) and leaves the flags alone.
     bool lanes_wait_pre = false;       // the lanes' launches of this call start behind what this call puts on the caller's stream first
+    // The STATISTICS words a captured render leaves alone: its replays add to whatever period they run in (pt_sync accepts multiples
+    // of a captured render's samples), and a fill inside the graph would wipe the counts of the direct renders of that period.
+    // They are zero whenever no render is pending -- cleared at their collection, at a scene upload and after a failure -- except
+    // that replays may have run since: once a render has been captured, a direct render that starts a period clears them itself.
     if (!accumulate) {
-        if (j.capturing || s.captured_any || !s.stats_clean) push(kOpMemsetStats, kStreamCaller);
+        if (!j.capturing && (s.captured_any || !s.stats_clean)) push(kOpMemsetStats, kStreamCaller);
         if (!j.capturing) s.stats_clean = 0;
         push(kOpRecord, kStreamCaller, kEvBegin);
         lanes_wait_pre = true;         // (the statistics' clearing -- here or at their collection -- is on that stream)
@@ -299,7 +305,7 @@ inline Plan plan(State& s, const Job& j, uint32_t faults = 0) {
             }
             if (lanes) {                     // the resolve (caller's stream) starts when the lane's launch is through
                 push(kOpRecord, ls, kEvLaneDone + lane);
-                push(kOpWait, kStreamCaller, kEvLaneDone + lane);
+                if (!(faults & kFaultResolveBeforeLaunch)) push(kOpWait, kStreamCaller, kEvLaneDone + lane);
             }
         }
         Op& r = push(kOpResolve, side);
@@ -324,7 +330,7 @@ inline void on_sync(State& s, bool collected, bool cleared_ok) {
     if (collected) { s.stats_clean = cleared_ok ? 1 : 0; s.stats_pending = 0; }
 }
 // pt_scene_upload: statistics of renders of the previous scene do not carry over
-inline void on_scene(State& s) { s.stats_pending = 0; s.stats_clean = 0; }
+inline void on_scene(State& s) { s.stats_pending = 0; s.stats_clean = 0; s.captured_any = 0; }
 // An operation of a render could not be enqueued.  The caller has waited for every stream (nothing is in flight any more); what
 // ran of the render left counters and statistics in an unknown state.  The rotation starts over, nothing is known to be clean.
 inline void on_failure(State& s, const State& planned) {

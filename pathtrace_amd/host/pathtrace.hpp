@@ -75,6 +75,13 @@ private:
     int code_;
 };
 inline void check(int rc) { if (rc != PT_OK) throw PtError(rc, pt_last_error()); }
+// A binary built against another ABI version of the header must not call into the library (struct sizes differ: PtStats grew in
+// version 4): every context of this mirror is created through here.
+inline void check_abi() {
+    if (pt_abi_version() != PT_ABI_VERSION)
+        throw std::runtime_error("pathtrace_amd: this program was built against ABI version " + std::to_string(PT_ABI_VERSION) +
+                                 " of include/pathtrace_amd.h, the library is version " + std::to_string(pt_abi_version()) + ": rebuild");
+}
 
 // ---- camera.rs:3-25
 struct Ray {
@@ -104,6 +111,7 @@ struct Probe {
     PtContext* ctx = nullptr;
     ~Probe() { if (ctx) pt_context_destroy(ctx); }
     PtContext* get(const PtObject& one) {
+        check_abi();
         if (!ctx && pt_context_create(0, &ctx) != PT_OK) throw std::runtime_error(std::string("pathtrace_amd: ") + pt_last_error());
         if (pt_scene_upload(ctx, &one, 1) != PT_OK) throw std::runtime_error(std::string("pathtrace_amd: ") + pt_last_error());
         return ctx;
@@ -481,6 +489,7 @@ private:
 
     // the context with this World's objects on it (uploaded again after push())
     PtContext* scene(int device) {
+        check_abi();
         if (!ctx_) check(pt_context_create(device, &ctx_));
         if (!uploaded_) { check(pt_scene_upload(ctx_, objects_.data(), (uint32_t)objects_.size())); uploaded_ = true; }
         return ctx_;

@@ -47,3 +47,18 @@ def test_cpu_baseline_leg_on_a_tiny_workload(bench, pt):
     assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
     assert out["all_cores"]["cores"] == len(os.sched_getaffinity(0)) and out["all_cores"]["value"] > 0
     assert out["config0_single_thread"]["cores"] == 1
+
+
+def test_the_timed_regions_counters_are_checked_against_the_job(bench):
+    """bench.py's own verification of its overlapped timed region: exact device counters, or a problem."""
+    per3 = {"vertices": 3 * 329_000_001, "shadow_rays": 3 * 250_000_007}
+    good = {"samples": 20 * 67_108_864, "samples_expected": 20 * 67_108_864, "vertices": 20 * 329_000_001, "shadow_rays": 20 * 250_000_007}
+    assert bench.counter_problems("t", good, 20 * 67_108_864, 20, per3, 3) == []
+    assert bench.counter_problems("t", good, 20 * 67_108_864, 20) == []
+    lost = dict(good, samples=int(good["samples"] * 0.97))                      # round 4's race: 3 % of the samples lost
+    assert any("finished" in p for p in bench.counter_problems("t", lost, 20 * 67_108_864, 20, per3, 3))
+    off = dict(good, vertices=good["vertices"] - 64)
+    assert any("vertices" in p for p in bench.counter_problems("t", off, 20 * 67_108_864, 20, per3, 3))
+    assert any("vertices" in p for p in bench.counter_problems("t", dict(good, vertices=good["vertices"] + 1), 20 * 67_108_864, 20))
+    wrong_job = bench.counter_problems("t", good, 19 * 67_108_864, 20, per3, 3)
+    assert wrong_job and "renders of the job" in wrong_job[0]

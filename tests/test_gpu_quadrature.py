@@ -357,6 +357,14 @@ def _ggx_sample(i, n, rough, color, metallic, ior, eta, r1, r2, u):
     return wo, f, pdf, cosv
 
 
+# Eval-side integral minus the sampler's mean weight for glass (mean over the channels), from the numpy restatement of
+# mirror.rs:17-305 with 2^18 draws: the reference's btdf() and its sampler disagree, more so at grazing incidence and for rough
+# surfaces (sampler / eval side: glass 0.999 / 1.002, 0.996 / 1.004, 0.969 / 0.998; rough glass 0.983 / 1.012, 0.949 / 1.040,
+# 0.890 / 1.145 at cos_i = 0.95, 0.6, 0.25).  Bounds = the value +- 0.005 (the sampler's mean carries ~6e-4 of noise).
+GLASS_GAP = {("glass", 0.95): (-0.0024, 0.0076), ("glass", 0.6): (0.0024, 0.0124), ("glass", 0.25): (0.0236, 0.0336),
+             ("rough glass", 0.95): (0.0247, 0.0347), ("rough glass", 0.6): (0.0859, 0.0959), ("rough glass", 0.25): (0.2506, 0.2606)}
+
+
 @pytest.mark.parametrize("mat", list(GGX_MATS))
 @pytest.mark.parametrize("cos_i", [0.95, 0.6, 0.25])
 def test_ggx_eval_and_sampler_against_the_formulas_of_mirror_rs(pt, gpu_ctx, mat, cos_i):
@@ -413,17 +421,54 @@ def test_ggx_eval_and_sampler_against_the_formulas_of_mirror_rs(pt, gpu_ctx, mat
     # glass they do NOT, in the reference itself: the sampler's transmission weight is (1 - F) G / G1 <= 1 by construction,
     # while btdf() (mirror.rs:90-124) takes |i.n|, |o.n| and has no test that the half vector faces the incident side, so it
     # is non-zero for directions no microfacet refracts into and its integral exceeds the sampler's mean (rough glass at
-    # grazing incidence: 1.15 against 0.89).  Both sides are pinned draw for draw / point for point above; here the
-    # glass figures are printed, the metal's asserted.
+    # grazing incidence: 1.15 against 0.89).  That inconsistency is the reference's and is reproduced on both sides; what
+    # is PINNED here (round 5; round 4 printed the figures) is that the device carries exactly it:
+    #   (1) the device sampler's mean weight = the numpy sampler's mean weight (same draws), 4 sigma of the paired difference;
+    #   (2) the device's eval-side integral = the numpy eval-side integral on the same quadrature grid;
+    #   (3) the gap between the two sides is the expected one (GLASS_GAP: a "fix" of either side on the device, or in the
+    #       numpy restatement, moves it) -- DESIGN.md 1 lists the rows.
     w = s[:, 3:6] * (s[:, 7] / s[:, 6])[:, None]
     mean, sem = w.mean(0), w.std(0, ddof=1) / np.sqrt(ns)
     assert np.all(mean <= 1.0 + 4.0 * sem)                                  # F G2 / G1 <= 1 per lobe (Heitz 2018)
+    w_ref = f * (cosv / pdf)[:, None]
+    mean_ref = w_ref.mean(0)
+    agree = (failed_gpu == failed_ref) & ((wo[:, 2] > 0) == (s[:, 2] > 0))   # draws on which no lobe pick / validity test flipped in f32
+    dw_pair = (w - w_ref)[agree]
+    sem_pair = dw_pair.std(0, ddof=1) / np.sqrt(len(dw_pair))
+    assert np.all(np.abs(dw_pair.mean(0)) <= 4.0 * sem_pair + 2e-4), (mat, cos_i, dw_pair.mean(0), sem_pair)
+    assert np.all(np.abs(mean - mean_ref) <= 4.0 * sem + 2e-3 * (1.0 - agree.mean()) + 2e-4), (mat, cos_i, mean, mean_ref, sem)
+    # (2) eval side on the device: the same midpoint rule on a grid the debug entry takes in one call
+    g_t, g_p = 500, 1000
+    gct = (np.arange(g_t) + 0.5) / g_t
+    gph = (np.arange(g_p) + 0.5) / g_p * 2 * np.pi
+    gctg, gphg = np.meshgrid(gct, gph, indexing="ij")
+    gstg = np.sqrt(1 - gctg * gctg)
+    gdw = (1.0 / g_t) * (2 * np.pi / g_p)
+    dev_total, ref_total = np.zeros(3), np.zeros(3)
+    for sign in (1.0, -1.0):
+        og = np.stack([gstg * np.cos(gphg), gstg * np.sin(gphg), sign * gctg], -1).reshape(-1, 3)
+        col = [1.0, 1.0, 1.0] if metallic > 0.99 else color
+        if metallic > 0.99 and sign < 0:
+            continue
+        inp = np.concatenate([np.tile(dir_in, (len(og), 1)), og, np.tile(n, (len(og), 1)), np.full((len(og), 1), eta)], 1)
+        if metallic > 0.99:      # (the metal's eval side is compared with F = 1, which needs another material record: numpy only)
+            ref_total += (_ggx_eval(i, og, n, rough, col, metallic, ior, eta) * gctg.reshape(-1, 1)).sum(0) * gdw
+            continue
+        got_f = gpu_ctx.debug_bsdf_eval(0, inp, exact_math=0).astype(np.float64)[:, :3]
+        dev_total += (got_f * gctg.reshape(-1, 1)).sum(0) * gdw
+        ref_total += (_ggx_eval(i, og, n, rough, col, metallic, ior, eta) * gctg.reshape(-1, 1)).sum(0) * gdw
     if metallic > 0.99:
         total = lobe_integral(1.0, [1.0, 1.0, 1.0])
         assert np.all(np.abs(mean - total) <= 4.0 * sem + 5e-3 * total), (mat, cos_i, mean, total, (mean - total) / sem)
     else:
         total = e_refl + e_trans
-    print(f"{mat}, cos_i {cos_i}: sampler mean weight {mean}, eval-side integral {total}")
+        assert np.all(np.abs(dev_total - ref_total) <= 2e-3 * ref_total), (mat, cos_i, dev_total, ref_total)
+        assert np.all(np.abs(ref_total - total) <= 1e-2 * total), (mat, cos_i, ref_total, total)          # the coarser grid is fine enough
+        # (3) the reference's own inconsistency, as a committed expectation: eval-side integral - sampler's mean weight
+        gap = float((total - mean_ref).mean())
+        lo, hi = GLASS_GAP[(mat, cos_i)]
+        assert lo <= gap <= hi, (mat, cos_i, gap, total, mean_ref)
+    print(f"{mat}, cos_i {cos_i}: sampler mean weight {mean} (numpy {mean_ref}), eval-side integral {total}")
 
 
 # ------------------------------------------------------------------ (iv) furnace: a convex Lambertian body inside a uniformly emitting sphere

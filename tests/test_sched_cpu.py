@@ -242,7 +242,7 @@ def test_a_captured_render_clears_what_it_uses_itself():
             cap = make_job(rng, form, n_batches=1, profile=0, in_order=0, fixed_grid=0, capturing=1)
             rc, graph, lanes = sch.render(cap)
             assert rc == 0 and not lanes
-            assert any(o.kind == S.K_MEMSET_COUNTERS for o in graph) and any(o.kind == S.K_MEMSET_STATS for o in graph)
+            assert any(o.kind == S.K_MEMSET_COUNTERS for o in graph) and not any(o.kind == S.K_MEMSET_STATS for o in graph)
             rc, ops, lanes = sch.render(job, 0, 5 if form == "regen" else 2)  # a direct render dies after its launch(es), before its resolve
             assert rc == 3 and any(o.kind == S.K_LAUNCH for o in ops) and not any(o.kind == S.K_RESOLVE for o in ops)
             try:

@@ -31,7 +31,7 @@ MUTANTS = [
     ("launch does not wait for the resolve that read its buffer set last",
      "if (s.set_used[par]) push(kOpWait, ls, kEvSetFree + par);", ";", "RC"),
     ("resolve does not wait for its lane's launch",
-     "push(kOpWait, kStreamCaller, kEvLaneDone + lane);", ";", "RD"),
+     "if (!(faults & kFaultResolveBeforeLaunch)) push(kOpWait, kStreamCaller, kEvLaneDone + lane);", ";", "RD"),
     ("lanes do not wait for the fills on the caller's stream",
      "if (lanes_wait_pre && !lane_waited_pre[lane]) { push(kOpWait, ls, kEvPre); lane_waited_pre[lane] = true; }", ";", "R"),
     ("the resolve does not clear the launch counters",
@@ -43,7 +43,7 @@ MUTANTS = [
     ("dirty launch counters are not cleared",
      "if (launch_words && (j.capturing || !s.counters_clean[par])) {", "if (false) {", "C"),
     ("dirty statistics are not cleared",
-     "if (j.capturing || s.captured_any || !s.stats_clean) push(kOpMemsetStats, kStreamCaller);", ";", "T"),
+     "if (!j.capturing && (s.captured_any || !s.stats_clean)) push(kOpMemsetStats, kStreamCaller);", ";", "T"),
     ("profiled renders take the lanes",
      "return kLaneOverlap && j.regen && j.regen_export <= 1u && !j.profile && !j.in_order && !j.capturing;",
      "return kLaneOverlap && j.regen && j.regen_export <= 1u && !j.in_order && !j.capturing;", "LP"),

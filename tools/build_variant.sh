@@ -11,5 +11,5 @@ mkdir -p /tmp/ptvar_$name
 /opt/rocm/bin/hipcc $FLAGS -DPT_MATH_EXACT=1 "$@" -c pt_kernels.hip -o /tmp/ptvar_$name/k1.o &
 /opt/rocm/bin/hipcc $FLAGS -DPT_MATH_EXACT=0 "$@" -c pt_kernels.hip -o /tmp/ptvar_$name/k0.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpt_$name.so /tmp/ptvar_$name/k1.o /tmp/ptvar_$name/k0.o pt_api.o pt_bvh.o pt_scenes.o pt_multi.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpt_$name.so /tmp/ptvar_$name/k1.o /tmp/ptvar_$name/k0.o pt_api.o pt_bvh.o pt_scenes.o pt_multi.o pt_sched.o -ldl
 echo "built pathtrace_amd/libpt_$name.so"

@@ -24,6 +24,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/bench_pmc_sq.json
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/bench_pmc_sq2.json
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_IOPS --output-format csv -d $OUT/pmc_sq3 -- python3 $ARGS > $OUT/bench_pmc_sq3.json
+# LDS: extra cycles lost to bank conflicts against all LDS-array cycles (BASELINE.md 3 asks for it on C4; MI355X_MICROARCH.md: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_lds -- python3 $ARGS > $OUT/bench_pmc_lds.json
 python3 tools/roofline_from_profile.py $OUT $TAG > $OUT/roofline_$TAG.json
 cat $OUT/roofline_$TAG.json
 # keep what is judged small: the stats / trace / counter CSVs, not the per-agent metadata

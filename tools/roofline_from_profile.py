@@ -81,6 +81,9 @@ if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
     out["clock_ghz_profiled"] = cyc / avg_ns if avg_ns else None
 if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
     out["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c["SQ_ACTIVE_INST_VALU"] else None
+if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
+    out["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    out["lds_note"] = "SQ_LDS_BANK_CONFLICT (extra cycles) / SQ_LDS_IDX_ACTIVE (all LDS-array cycles), MI355X_MICROARCH.md"
 mix = {k[len("SQ_INSTS_VALU_"):]: v for k, v in c.items() if k.startswith("SQ_INSTS_VALU_")}
 if mix:
     out["valu_mix_per_launch"] = mix
