@@ -67,7 +67,7 @@ F_SPHERE, F_TRIANGLE, F_SHADE = 23, 51, 200     # flops per primiti
 # triangles of one parallelogram TOGETHER (tripair_test: determinant, t and hit point once = 20, then 2 x 11): the model prices
 # what is executed, so that `frac` does not credit work nobody does.
 F_TRIANGLE_PLANE, F_TRIANGLE_PAIR = 31, 42
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 REGEN_MIN_PATHS = 1 << 17     # pt_api.cpp kRegenMinPaths: batches above this over a scene in LDS take a regenerating form
 
 

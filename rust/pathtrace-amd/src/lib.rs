@@ -68,8 +68,19 @@ pub struct Renderer {
 }
 unsafe impl Send for Renderer {}
 
+/// The library must be the ABI version these declarations were written for (struct sizes differ between versions:
+/// `PtStats` grew in version 4).  Checked before any context exists.
+fn check_abi() -> Result<(), Error> {
+    let lib = unsafe { sys::pt_abi_version() };
+    if lib != sys::PT_ABI_VERSION {
+        return Err(Error { code: sys::PT_ERR_UNSUPPORTED as i32, message: format!("pathtrace-amd-sys declares ABI version {}, the library is version {}", sys::PT_ABI_VERSION, lib) });
+    }
+    Ok(())
+}
+
 impl Renderer {
     pub fn new(device: i32) -> Result<Self, Error> {
+        check_abi()?;
         let mut ctx = std::ptr::null_mut();
         check(unsafe { sys::pt_context_create(device, &mut ctx) })?;
         Ok(Renderer { ctx })
@@ -175,6 +186,7 @@ unsafe impl Send for Multi {}
 
 impl Multi {
     pub fn new(devices: &[i32]) -> Result<Self, Error> {
+        check_abi()?;
         let mut m = std::ptr::null_mut();
         check(unsafe { sys::pt_multi_create(devices.as_ptr(), devices.len() as u32, &mut m) })?;
         Ok(Multi { m })
