@@ -174,14 +174,16 @@ def counter_problems(tag, timed, want_samples, steps, ref=None, ref_steps=0):
     return problems
 
 
-def profile_summary(world, workload, accel):
+def profile_summary(world, workload, accel, level0_form=0):
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 passes of THIS command
-    (profiles/r03/roofline_<workload>[_bvh].json, written by tools/profile_workload.sh on the GPU box).  PMC counters
+    (profiles/r05/roofline_<workload>[_bvh | _queue].json, written by tools/profile_workload.sh on the GPU box).  PMC counters
     cannot be read from inside this process, so these are the last profiled values, tagged with their source file;
     None when no profile of this exact workload exists (or N > 1)."""
     if world != 1:
         return None
-    name = f"roofline_{workload}{'_bvh' if accel == 1 else ''}.json"
+    if level0_form not in (0, 1):
+        return None         # a forced regenerating form has no committed profile of its own
+    name = f"roofline_{workload}{'_bvh' if accel == 1 else ''}{'_queue' if level0_form == 1 else ''}.json"
     path = os.path.join(PROFILE_DIR, name)
     if not os.path.exists(path):
         return None
@@ -496,7 +498,7 @@ def main(argv=None):
         achieved_tf = alg_flops / (acc["p_ms"] * 1e-3) / 1e12 if acc["p_ms"] > 0 else 0.0
         alg_bytes = (BYTES_PER_VERTEX * acc["p_vertices"] + BYTES_PER_SAMPLE * acc["samples"]) / n_stat
         avg_ms = acc["p_ms"] / max(p_launches, 1)
-        prof = profile_summary(world if mode != "multi" else 0, args.workload, args.accel)
+        prof = profile_summary(world if mode != "multi" else 0, args.workload, args.accel, args.level0_form)
         accel_name = {0: "linear scan (reference)", 1: "BVH traversal (accel=1, same film as the linear scan)",
                       2: "PT_ACCEL_AUTO (product default: BVH above ~512 sphere tests per scan, same film)"}[args.accel]
         diffuse = all(o.mat_tag in (0, 1) for o in objs)

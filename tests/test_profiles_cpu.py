@@ -1,5 +1,5 @@
-"""The evidence chain of bench.py's `roofline` object, on the CPU: the committed rocprofv3 passes under profiles/r04/<tag>/ condense (tools/
-roofline_from_profile.py) into exactly the committed profiles/r04/roofline_<tag>.json that bench.py replays (`counters_source`), and the
+"""The evidence chain of bench.py's `roofline` object, on the CPU: the committed rocprofv3 passes under profiles/r05/<tag>/ condense (tools/
+roofline_from_profile.py) into exactly the committed profiles/r05/roofline_<tag>.json that bench.py replays (`counters_source`), and the
 launch times in it agree with what the bench lines of the same commit report."""
 import json
 import os
@@ -9,10 +9,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r04")
+PROF = os.path.join(ROOT, "profiles", "r05")
 
 
-@pytest.mark.parametrize("tag", ["c2", "c1", "c4_bvh"])
+@pytest.mark.parametrize("tag", ["c2", "c1", "c2_queue", "c4", "c4_bvh"])
 def test_committed_profile_condenses_to_the_committed_summary(tag):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_from_profile.py"), os.path.join(PROF, tag), tag],
                          check=True, capture_output=True, text=True).stdout
