@@ -518,7 +518,7 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
         bool pair = false;
         if (tri && i + 1 < n && objs[i + 1].shape_tag == PT_SHAPE_TRIANGLE) {
             const float4 *a = &obj_scan[3 * (size_t)i], *b = &obj_scan[3 * (size_t)i + 3];
-            pair = std::memcmp(&a[0], &b[0], sizeof(float4)) == 0 && std::memcmp(&a[1], &b[1], 2 * sizeof(float)) == 0;
+            pair = std::memcmp(&a[0], &b[0], 3 * sizeof(float)) == 0 && std::memcmp(&a[1], &b[1], 3 * sizeof(float)) == 0;   // n, v0
         }
         const uint32_t tag = !tri ? (uint32_t)ptk::kRunSphere : pair ? (uint32_t)ptk::kRunTrianglePair : (uint32_t)ptk::kRunTriangle;
         if (runs.empty() || runs.back().tag != tag) {
@@ -527,11 +527,17 @@ int pt_scene_upload(PtContext* c, const PtObject* objs, uint32_t n) {
             runs.push_back(r);
         }
         runs.back().count++;
-        scan.insert(scan.end(), &obj_scan[3 * (size_t)i], &obj_scan[3 * (size_t)i] + obj_ns[i]);
-        if (pair) {      // the second triangle's barycentric gradients N1, N2 (its v0 and n are the first's)
-            const float4* b = &obj_scan[3 * (size_t)i + 3];
-            scan.push_back(make_float4(b[1].z, b[1].w, b[2].x, b[2].y));
-            scan.push_back(make_float4(b[2].z, b[2].w, 0.f, 0.f));
+        if (!pair) scan.insert(scan.end(), &obj_scan[3 * (size_t)i], &obj_scan[3 * (size_t)i] + obj_ns[i]);
+        if (pair) {
+            // pair record, 5 float4 in the order tripair_test reads them: (n, -) (v0, -) and then the four barycentric gradients
+            // back to back from a 16-byte boundary -- (N1, N2.x) (N2.y, N2.z, N1'.x, N1'.y) (N1'.z, N2') -- so that the part only
+            // rays inside the pair's t range read is three aligned 16-byte reads (round 5; before: five 8-byte pieces)
+            const float4 *a = &obj_scan[3 * (size_t)i], *b = &obj_scan[3 * (size_t)i + 3];
+            scan.push_back(make_float4(a[0].x, a[0].y, a[0].z, 0.f));
+            scan.push_back(make_float4(a[1].x, a[1].y, a[1].z, 0.f));
+            scan.push_back(make_float4(a[0].w, a[1].w, a[2].x, a[2].y));
+            scan.push_back(make_float4(a[2].z, a[2].w, b[0].w, b[1].w));
+            scan.push_back(make_float4(b[2].x, b[2].y, b[2].z, b[2].w));
         }
         i += pair ? 2u : 1u;
     }

@@ -71,15 +71,17 @@ struct Built {
 //     N1 = (e2 x n) / (n.n)        u = (s + t d) . N1                    (N1.e1 = 1, N1.e2 = 0, N1.n = 0)
 //     N2 = (n x e1) / (n.n)        v = (s + t d) . N2                    (N2.e2 = 1, N2.e1 = 0, N2.n = 0)
 // computed in f64 from the f32 edges and rounded to f32 (the oracle's float instantiation does the same, bit for bit).
-// Packing, 3 float4: (v0.x, v0.y, v0.z, n.x) (n.y, n.z, N1.x, N1.y) (N1.z, N2.x, N2.y, N2.z).
+// Packing, 3 float4, in the order the test reads them -- one aligned 16-byte read per stage (round 5; rounds 3-4 packed v0 first
+// and the compiler read the normal as two 8-byte halves of two float4): (n.x, n.y, n.z, N1.x) (v0.x, v0.y, v0.z, N1.y)
+// (N1.z, N2.x, N2.y, N2.z).
 inline void triangle_scan_record(const float4& v0, const float4& e1f, const float4& e2f, float4 out[3]) {
     const double e1[3] = {e1f.x, e1f.y, e1f.z}, e2[3] = {e2f.x, e2f.y, e2f.z};
     const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
     const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
     const double a[3] = {e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0]};   // e2 x n
     const double b[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};   // n x e1
-    out[0] = make_float4(v0.x, v0.y, v0.z, (float)n[0]);
-    out[1] = make_float4((float)n[1], (float)n[2], (float)(a[0] / nn), (float)(a[1] / nn));
+    out[0] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(a[0] / nn));
+    out[1] = make_float4(v0.x, v0.y, v0.z, (float)(a[1] / nn));
     out[2] = make_float4((float)(a[2] / nn), (float)(b[0] / nn), (float)(b[1] / nn), (float)(b[2] / nn));
 }
 

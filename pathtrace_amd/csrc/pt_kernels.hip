@@ -43,6 +43,12 @@ using namespace ptk;
 #define PT_LAUNCH(name) name##_fast
 #endif
 
+#ifndef PT_PAIR_FLAT
+#define PT_PAIR_FLAT 0          // measured (round 5): C1 7.46 -> 7.92 ms per launch -- profiles/r05/ab_c1_replace_flat.txt
+#endif
+#ifndef PT_SPHERE_FLAT
+#define PT_SPHERE_FLAT 0        // measured (round 5): C2 5.54 -> 5.55 ms per launch, nothing -- profiles/r05/ab_noslp.txt
+#endif
 namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ primitive tests
@@ -84,22 +90,22 @@ PT_DEV void sphere_test(float4 s, f3 o, f3 d, float t_min, float& closest, int& 
 // for predicate: |a| < 1e-8 rejects (:169), u outside [0, 1] rejects, NaN included (RangeInclusive::contains, :176),
 // v < 0 or u + v > 1 rejects (:183), t outside [t_min, closest] rejects (:190); t == closest is accepted (last wins).
 // They form one conjunction, so testing the t range first (it is known first here) changes nothing.
-// Record: r0 = (v0, n.x), r1 = (n.y, n.z, N1.x, N1.y), r2 = (N1.z, N2.xyz).
+// Record: r0 = (n, N1.x), r1 = (v0, N1.y), r2 = (N1.z, N2.xyz) -- one 16-byte read per stage of the test.
 template <bool ORDERED = false, bool ANY = false>
 PT_DEV void triangle_test(float4 r0, float4 r1, float4 r2, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
-    const f3 n = mk(r0.w, r1.x, r1.y);
+    const f3 n = mk(r0.x, r0.y, r0.z);
     const float det = dot(d, n);
     if (__builtin_fabsf(det) < 1e-8f) return;
-    const f3 s = o - mk(r0.x, r0.y, r0.z);
+    const f3 s = o - mk(r1.x, r1.y, r1.z);
     const float t = pt_div(-dot(s, n), det);
 #ifdef PT_TRI_BRANCHLESS      // measurement variant: one reject at the end instead of three early-outs
     const f3 p = madd(d, t, s);
-    const float u = dot(p, mk(r1.z, r1.w, r2.x)), v = dot(p, mk(r2.y, r2.z, r2.w));
+    const float u = dot(p, mk(r0.w, r1.w, r2.x)), v = dot(p, mk(r2.y, r2.z, r2.w));
     if (t < t_min || t > closest || !(u >= 0.0f && u <= 1.0f) || v < 0.0f || u + v > 1.0f) return;
 #else
     if (t < t_min || t > closest) return;
     const f3 p = madd(d, t, s);                      // hit point relative to v0
-    const float u = dot(p, mk(r1.z, r1.w, r2.x));
+    const float u = dot(p, mk(r0.w, r1.w, r2.x));
     if (!(u >= 0.0f && u <= 1.0f)) return;         // RangeInclusive::contains: NaN rejected
     const float v = dot(p, mk(r2.y, r2.z, r2.w));
     if (v < 0.0f || u + v > 1.0f) return;
@@ -114,27 +120,41 @@ PT_DEV void triangle_test(float4 r0, float4 r1, float4 r2, f3 o, f3 d, float t_m
 // triangle_test would compute twice -- determinant, t, the range test, the hit point -- is computed once.  The second test's
 // range check "t <= closest" holds either way: closest is unchanged, or the first triangle was just accepted at this t (and
 // the second, accepted too, wins the tie as the later object: world.rs:281-287).  Same results as two triangle_test calls.
-// Record: r0..r2 = the first triangle's, r3 = (N1.xyz, N2.x), r4 = (N2.y, N2.z, -, -) of the second.
+// Record (pt_scene_upload): r0 = (n, -), r1 = (v0, -), r2 = (N1, N2.x), r3 = (N2.y, N2.z, N1'.x, N1'.y), r4 = (N1'.z, N2').
 template <bool ANY = false>
 PT_DEV void tripair_test(float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
-    const f3 n = mk(r0.w, r1.x, r1.y);
+    const f3 n = mk(r0.x, r0.y, r0.z);
     const float det = dot(d, n);
     if (__builtin_fabsf(det) < 1e-8f) return;
-    const f3 s = o - mk(r0.x, r0.y, r0.z);
+    const f3 s = o - mk(r1.x, r1.y, r1.z);
     const float t = pt_div(-dot(s, n), det);
     if (t < t_min || t > closest) return;
     const f3 p = madd(d, t, s);
-    const float u0 = dot(p, mk(r1.z, r1.w, r2.x));
+#if PT_PAIR_FLAT
+    // measurement variant: both triangles' barycentric tests without branches (same predicates on the same values; a wave of
+    // incoherent rays nearly always has a lane inside each u range, so the branches skip little and cost scalar instructions)
+    {
+        const float u0 = dot(p, mk(r2.x, r2.y, r2.z)), v0 = dot(p, mk(r2.w, r3.x, r3.y));
+        const float u1 = dot(p, mk(r3.z, r3.w, r4.x)), v1 = dot(p, mk(r4.y, r4.z, r4.w));
+        const bool acc0 = (u0 >= 0.0f && u0 <= 1.0f) && !(v0 < 0.0f || u0 + v0 > 1.0f);
+        const bool acc1 = (u1 >= 0.0f && u1 <= 1.0f) && !(v1 < 0.0f || u1 + v1 > 1.0f);
+        if (ANY) { if (acc0 || acc1) id = 0; return; }
+        closest = (acc0 || acc1) ? t : closest;
+        id = acc1 ? obj + 1 : acc0 ? obj : id;
+        return;
+    }
+#endif
+    const float u0 = dot(p, mk(r2.x, r2.y, r2.z));
     if (u0 >= 0.0f && u0 <= 1.0f) {
-        const float v0 = dot(p, mk(r2.y, r2.z, r2.w));
+        const float v0 = dot(p, mk(r2.w, r3.x, r3.y));
         if (!(v0 < 0.0f || u0 + v0 > 1.0f)) {
             if (ANY) { id = 0; return; }
             closest = t; id = obj;
         }
     }
-    const float u1 = dot(p, mk(r3.x, r3.y, r3.z));
+    const float u1 = dot(p, mk(r3.z, r3.w, r4.x));
     if (u1 >= 0.0f && u1 <= 1.0f) {
-        const float v1 = dot(p, mk(r3.w, r4.x, r4.y));
+        const float v1 = dot(p, mk(r4.y, r4.z, r4.w));
         if (!(v1 < 0.0f || u1 + v1 > 1.0f)) {
             if (ANY) { id = 0; return; }
             closest = t; id = obj + 1;
@@ -153,6 +173,20 @@ PT_DEV void sphere_pre(float4 s, f3 o, f3 d, float& half_b, float& disc) {
 }
 template <bool ANY>
 PT_DEV void sphere_post(float half_b, float disc, float t_min, float& closest, int& id, int obj) {
+#if PT_SPHERE_FLAT
+    // measurement variant: no branch on the discriminant (the root of a negative one is a NaN nobody reads)
+    {
+        const float sq = pt_sqrt(disc);
+        const float ra = -half_b - sq, rb = -half_b + sq;
+        const float cc = ra < t_min ? rb : ra;
+        const bool rej = disc < 0.0f || cc < t_min || closest < cc;
+        if (ANY) { id = rej ? id : 0; return; }
+        closest = rej ? closest : cc;
+        id = rej ? id : obj;
+        __builtin_amdgcn_sched_barrier(0);      // (one test after the other: interleaved, four of them need 30 registers more)
+        return;
+    }
+#endif
     if (disc < 0.0f) return;
     float sqrtd = pt_sqrt(disc);
     float root1 = -half_b - sqrtd;
@@ -349,6 +383,7 @@ PT_DEV uint32_t image_row(const TileMap& t, uint32_t yl) {
 #ifndef PT_WG_TOTALS
 #define PT_WG_TOTALS 1
 #endif
+
 struct WgTotals { uint32_t done, shadow, vertices, samples, dmax; };
 PT_DEV void wg_totals_init(WgTotals& t) {                 // by one thread, before the workgroup's first barrier
     t.done = 0u; t.shadow = 0u; t.vertices = 0u; t.samples = 0u; t.dmax = 0u;
@@ -462,11 +497,14 @@ PT_DEV void camera_ray(const CameraF& cam, uint32_t sample, uint32_t px, uint32_
 //   kMatsAll       every material
 //   kMatsDiffuse   Lambertian and emissive only (scene property, decided at pt_scene_upload): no GGX, no OrenNayar code
 //   kMatsNoMirror  everything but Mirror (the plain iterations of k_paths_regen_split, which hand Mirror vertices on)
-constexpr int kMatsAll = 0, kMatsDiffuse = 1, kMatsNoMirror = 2;
+//   kMatsMirror    the object HIT is a Mirror (the batches of k_paths_regen_split: every entry of the special stack is one);
+//                  says nothing about the light's material
+constexpr int kMatsAll = 0, kMatsDiffuse = 1, kMatsNoMirror = 2, kMatsMirror = 3;
 template <int MATS>
 PT_DEV void assume_mats(uint32_t tag) {
     if (MATS == kMatsDiffuse) __builtin_assume(tag <= MAT_EMISSIVE);
     if (MATS == kMatsNoMirror) __builtin_assume(tag != MAT_MIRROR);
+    if (MATS == kMatsMirror) __builtin_assume(tag == MAT_MIRROR);
 }
 template <int DIFFUSE>
 PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, uint32_t w_r1, uint32_t w_r2, f3& point,
@@ -474,7 +512,7 @@ PT_DEV void sample_light_point(const SceneRef& sc, f3 from, uint32_t w_index, ui
     const uint32_t li = __umulhi(w_index, sc.n_lights);                           // random_range(0..n), world.rs:255
     lobj = (int)sc.lights[li];
     const Mat lm = load_mat(sc.mat, lobj);
-    assume_mats<DIFFUSE>(lm.tag);
+    if (DIFFUSE != kMatsMirror) assume_mats<DIFFUSE>(lm.tag);
     float pdf_shape;
     shape_sample(sc.shape, sc.mat, lobj, lm.shape_tag, from, false, from, u01(w_r1), u01(w_r2), point, pdf_shape, dir, dist);
     emission = lm.color;                                                          // world.rs:259
@@ -551,7 +589,8 @@ PT_DEV bool vertex_end(const SceneRef& sc, PathState& p, const Vertex& vin, bool
         v.m = load_mat(sc.mat, vin.obj);
         v.ls_emission = load_mat(sc.mat, vin.light_obj).color;
     }
-    assume_mats<DIFFUSE>(v.m.tag);
+    if (DIFFUSE != kMatsMirror) assume_mats<DIFFUSE>(v.m.tag);
+    else if (vin.alive) assume_mats<DIFFUSE>(v.m.tag);         // (a lane without a path re-reads object 0's material)
     if (vin.hit_emitter) {
         if (!MIS || p.depth == 0u) {
             p.L = p.L + p.beta * v.m.color;                                       // rendering.rs:44-45 / :225-227
@@ -1188,22 +1227,34 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
 //     stack with its (id, t); anything else -> onto the wave's PLAIN stack, from which the regeneration step of the plain
 //     iterations takes entries before it takes camera rays.  Then the plain paths come back into the lanes.
 // Both stacks share one 128-entry region per wave in global memory (L2-resident: 10 KB per wave), special growing up, plain
-// growing down.  They cannot collide: paths enter a wave only through camera-ray
-// regeneration, which happens only when the plain stack is empty and (batches run whenever >= 64 specials wait) at most
-// 63 specials wait, so lanes + stacks never hold more than 127 paths.  No atomics, no other wave involved.
+// growing down.  They cannot collide.  Let S, P be the entries of the two stacks.  At the top of an iteration S <= 63 (batches
+// run whenever >= 64 specials wait).  A plain iteration finds f <= 64 Mirror vertices; each of the first min(f, P) takes an
+// entry OFF the plain stack as it puts one ON the special stack (PT_SPLIT_REPLACE, round 5: S + P unchanged), the others push
+// with the plain stack empty, so afterwards S + P <= max(S + P before, 63 + 64).  A batch takes 64 entries off the special
+// stack and puts at most 64 back on either: S + P does not grow.  Hence S + P <= 127 < 128 always.  (Round 3-4 form, without
+// the replacement: lanes take plain entries before camera rays, so a push finds the plain stack empty.)  No atomics, no other
+// wave involved; a violated invariant sets stats[7] and pt_sync fails.
 // Same per-vertex functions on the same inputs as every other form (a path's arithmetic does not depend on which lane
 // or in which order it is traced), so the film is bit-identical (test_level0_forms_give_the_same_film, the fuzz tests).
 constexpr int kWaitVm0 = 0x0F70;                                 // s_waitcnt vmcnt(0) alone (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
 constexpr uint32_t kXq = 128;                                    // exchange entries per wave
 constexpr uint32_t kXqEntryF4 = 5;                               // stack entry: 4 float4 of path state (layout of Queue) + (bits(id), t, -, -)
 constexpr uint32_t kXqF4PerWave = kXq * kXqEntryF4;               // the stacks (round 3 also parked the wave's 64 plain paths here: LDS since round 4, ab_c1_park_in_lds.txt)
+#ifndef PT_SPLIT_REPLACE
+#define PT_SPLIT_REPLACE 1       // measured (round 5): 7.40 -> 7.30 ms per C1 launch -- profiles/r05/ab_c1_replace_flat.txt, ab_noslp.txt
+#endif
+#ifndef PT_SPLIT_BATCH_MATS
+#define PT_SPLIT_BATCH_MATS kMatsAll      // kMatsMirror: the batch's vertex code compiled for Mirror hits only (measurement)
+#endif
 #ifndef PT_SPLIT_STAY
 #define PT_SPLIT_STAY 0          // measured (round 5): 7.52 -> 7.62 ms per C1 launch at every threshold tried -- profiles/r05/ab_c1_stay_in_lane.txt
 #endif
 #ifndef PT_SPLIT_STAY_MIN
 #define PT_SPLIT_STAY_MIN 32
 #endif
+#if PT_SPLIT_STAY
 constexpr uint32_t kSplitStayMin = PT_SPLIT_STAY_MIN;             // a batch goes on while at least this many specials are in lanes + waiting
+#endif
 static_assert(kXqF4PerWave == kRegenSplitF4PerWave, "pt_kernels.h sizes the buffer");
 // One wave-uniform base pointer (two scalar registers); entry-major, so the planes of an entry are immediate offsets of
 // ONE address -- with plane-major arrays the compiler kept a scalar base per plane (24 SGPRs more than the kernel has).
@@ -1298,14 +1349,27 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
         }
         __builtin_amdgcn_wave_barrier();
         // ---- lanes without a path: first the plain stack (paths that left a Mirror surface), then the ring
+        // (PT_SPLIT_REPLACE: the ring first -- what waits on the plain stack has its next vertex scanned already and takes the place
+        // of the lanes that find a Mirror vertex below; the lanes here take it only when the ring cannot serve them: the end of the batch)
         {
             const unsigned long long need = __ballot(!alive);
             const uint32_t r = lane_rank(need);
             const uint32_t n_need = (uint32_t)__popcll(need);
+#if PT_SPLIT_REPLACE
+            const uint32_t n_ring = n_need < pool_cnt ? n_need : pool_cnt;
+            const uint32_t n_pq = n_need - n_ring < pq_cnt ? n_need - n_ring : pq_cnt;
+            const bool from_pq = !alive && r >= n_ring && r - n_ring < n_pq;
+            const bool from_ring = !alive && r < n_ring;
+            const uint32_t e_pq = kXq - pq_cnt + (r - n_ring), e_ring = (pool_head + r) & (kPool - 1u);
+#else
             const uint32_t n_pq = n_need < pq_cnt ? n_need : pq_cnt;
-            if (!alive && r < n_pq) {
-                const uint32_t e = kXq - pq_cnt + r;
-                const float4* src = x.entry(e);
+            const uint32_t n_ring = n_need - n_pq < pool_cnt ? n_need - n_pq : pool_cnt;
+            const bool from_pq = !alive && r < n_pq;
+            const bool from_ring = !alive && r >= n_pq && r - n_pq < pool_cnt;
+            const uint32_t e_pq = kXq - pq_cnt + r, e_ring = (pool_head + r - n_pq) & (kPool - 1u);
+#endif
+            if (from_pq) {
+                const float4* src = x.entry(e_pq);
                 p = unpack_state(src[0], src[1], src[2], src[3]);
                 // all four loads back HERE: otherwise the compiler waits (vmcnt(0)) at the first use of beta / L in the
                 // iteration below, on every path -- and on gfx9 that counter also holds the previous iteration's
@@ -1313,10 +1377,9 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 // branch: 7.5 instead of 6.2 ms)
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);
                 alive = true;
-            } else if (!alive && r - n_pq < pool_cnt) {
-                const uint32_t e = (pool_head + r - n_pq) & (kPool - 1u);
-                const float4 q = pool_d[e];
-                const uint32_t sd = pool_s[e];
+            } else if (from_ring) {
+                const float4 q = pool_d[e_ring];
+                const uint32_t sd = pool_s[e_ring];
                 p.o = cam_o; p.d = mk(q.x, q.y, q.z);
                 const uint32_t xy = __float_as_uint(q.w);
                 p.yl = xy >> 16; p.px = xy & 0xFFFFu;
@@ -1326,7 +1389,6 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 alive = true;
             }
             pq_cnt -= n_pq;
-            const uint32_t n_ring = n_need - n_pq < pool_cnt ? n_need - n_pq : pool_cnt;
             pool_head += n_ring; pool_cnt -= n_ring;
             if (PT_COUNT_FINISHED) wave_taken += n_ring;
         }
@@ -1343,6 +1405,41 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
             const bool special = alive && id >= 0 && is_mirror_obj(sc, id);
             const unsigned long long spm = __ballot(special);
             if (spm != 0ull) {
+#if PT_SPLIT_REPLACE
+                // Round 5: a lane that hands its path to the special stack takes, in the same breath, a path from the plain stack --
+                // one that left the glass in an earlier batch, whose next vertex that batch has scanned already: (id, t) travel with
+                // the entry.  The lane goes on with vertex_begin at once instead of idling through the rest of the iteration, and the
+                // path is not scanned a second time.  The pops are complete before the pushes are issued (with both stacks nearly
+                // full the pushed entries may be the popped ones); lanes + stacks stay <= 127 paths: a push without a pop happens
+                // only with the plain stack empty, i.e. at <= 63 + 64 entries.
+                const uint32_t rk = lane_rank(spm);
+                const uint32_t n_sp = (uint32_t)__popcll(spm);
+                const uint32_t n_rep = n_sp < pq_cnt ? n_sp : pq_cnt;
+                const bool rep = special && rk < n_rep;
+                PathState q = p;
+                int qid = -1; float qt = 0.0f;
+                if (rep) {
+                    const float4* src = x.entry(kXq - pq_cnt + rk);
+                    q = unpack_state(src[0], src[1], src[2], src[3]);
+                    const float2 it = *reinterpret_cast<const float2*>(src + 4);
+                    qid = __float_as_int(it.x); qt = it.y;
+                    __builtin_amdgcn_s_waitcnt(kWaitVm0);
+                }
+                if (special) {
+                    float4* dst = x.entry(sq_cnt + rk);
+                    store_entry(dst, p);
+                    *reinterpret_cast<float2*>(dst + 4) = make_float2(__int_as_float(id), t);
+                    if (rep) {
+                        p = q; id = qid; t = qt;
+                    } else {
+                        alive = false;
+                        p.o = parked_origin(); p.d = parked_dir();
+                        id = -1;
+                    }
+                }
+                sq_cnt += n_sp;
+                pq_cnt -= n_rep;
+#else
                 if (special) {
                     float4* dst = x.entry(sq_cnt + lane_rank(spm));
                     store_entry(dst, p);
@@ -1352,6 +1449,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                     id = -1;
                 }
                 sq_cnt += (uint32_t)__popcll(spm);
+#endif
                 overflow = overflow || sq_cnt + pq_cnt > kXq;
             }
             const bool active = alive;
@@ -1421,7 +1519,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const uint32_t sample = a.s_base + q.s_local;
                 wave_vertices += n_stay;
                 Vertex v;
-                vertex_begin<MIS, kMatsAll>(sc, q, qa, qid, qt, sample, kx, py, v);
+                vertex_begin<MIS, PT_SPLIT_BATCH_MATS>(sc, q, qa, qid, qt, sample, kx, py, v);
                 bool visible = false;
                 if (MIS) {
                     const unsigned long long sm = __ballot(v.need_shadow);
@@ -1434,7 +1532,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                         wave_shadow += (uint32_t)__popcll(sm);
                     }
                 }
-                const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
+                const bool qalive = vertex_end<MIS, PT_SPLIT_BATCH_MATS, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
                 if (qa && !qalive) {
                     a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
                     dmax = q.depth > dmax ? q.depth : dmax;
@@ -1484,7 +1582,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const uint32_t sample = a.s_base + q.s_local;
                 wave_vertices += n;
                 Vertex v;
-                vertex_begin<MIS, kMatsAll>(sc, q, qa, qid, qt, sample, kx, py, v);
+                vertex_begin<MIS, PT_SPLIT_BATCH_MATS>(sc, q, qa, qid, qt, sample, kx, py, v);
                 bool visible = false;
                 if (MIS) {
                     const unsigned long long sm = __ballot(v.need_shadow);
@@ -1497,7 +1595,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                         wave_shadow += (uint32_t)__popcll(sm);
                     }
                 }
-                const bool qalive = vertex_end<MIS, kMatsAll, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
+                const bool qalive = vertex_end<MIS, PT_SPLIT_BATCH_MATS, true>(sc, q, v, visible, sample, kx, py, a.min_depth, a.max_depth);
                 if (qa && !qalive) {
                     a.lsamp[q.s_local * a.np + q.yl * W + q.px] = Rgb{q.L.x, q.L.y, q.L.z};
                     dmax = q.depth > dmax ? q.depth : dmax;
@@ -1515,7 +1613,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                     const uint32_t dst = spec2 ? sq_cnt + lane_rank(m_s) : kXq - pq_cnt - n_p + lane_rank(m_p);
                     float4* de = x.entry(dst);
                     store_entry(de, q);
-                    if (spec2) *reinterpret_cast<float2*>(de + 4) = make_float2(__int_as_float(id2), t2);
+                    if (spec2 || PT_SPLIT_REPLACE) *reinterpret_cast<float2*>(de + 4) = make_float2(__int_as_float(id2), t2);
                 }
                 sq_cnt += (uint32_t)__popcll(m_s);
                 pq_cnt += n_p;

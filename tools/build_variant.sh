@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../pathtrace_amd/csrc"
 name=$1; shift
 make -j4 >/dev/null
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-parameter"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-parameter"
 mkdir -p /tmp/ptvar_$name
 /opt/rocm/bin/hipcc $FLAGS -DPT_MATH_EXACT=1 "$@" -c pt_kernels.hip -o /tmp/ptvar_$name/k1.o &
 /opt/rocm/bin/hipcc $FLAGS -DPT_MATH_EXACT=0 "$@" -c pt_kernels.hip -o /tmp/ptvar_$name/k0.o &

@@ -5,7 +5,7 @@ import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 exact = "--exact" in sys.argv
 extra = [a for a in sys.argv[1:] if a != "--exact"]
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
        f"-DPT_MATH_EXACT={1 if exact else 0}", "-Rpass-analysis=kernel-resource-usage", "-c", "pt_kernels.hip", "-o", "/dev/null"] + extra
 out = subprocess.run(cmd, cwd=os.path.join(ROOT, "pathtrace_amd", "csrc"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
 rows, cur = [], None
