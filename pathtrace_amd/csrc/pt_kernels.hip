@@ -43,6 +43,18 @@ using namespace ptk;
 #define PT_LAUNCH(name) name##_fast
 #endif
 
+#ifndef PT_PAIR_PREFETCH
+#define PT_PAIR_PREFETCH 1      // 1: the next pair's normal one pair ahead (C1 launch 7.16 -> 7.07 ms); 2: its v0 too (2 spilled registers, 7.17) -- profiles/r05/ab_lds_latency.txt
+#endif
+#ifndef PT_SPHERE_REM2
+#define PT_SPHERE_REM2 1
+#endif
+#ifndef PT_RUN0_SGPR
+#define PT_RUN0_SGPR 0          // measured (round 5): C1 launch +1.7 %, C2 +0.3 % -- profiles/r05/ab_lds_latency.txt
+#endif
+#ifndef PT_PAIR_S_EARLY
+#define PT_PAIR_S_EARLY 0       // measured (round 5): C1 launch 7.09 -> 7.05 / 7.17 ms without / with the prefetch -- profiles/r05/ab_pair_s_early.txt
+#endif
 #ifndef PT_PAIR_FLAT
 #define PT_PAIR_FLAT 0          // measured (round 5): C1 7.46 -> 7.92 ms per launch -- profiles/r05/ab_c1_replace_flat.txt
 #endif
@@ -125,8 +137,16 @@ template <bool ANY = false>
 PT_DEV void tripair_test(float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, f3 o, f3 d, float t_min, float& closest, int& id, int obj) {
     const f3 n = mk(r0.x, r0.y, r0.z);
     const float det = dot(d, n);
+#if PT_PAIR_S_EARLY
+    // measurement variant: o - v0 before the determinant's test, so that v0 is requested together with the normal (one dependent LDS
+    // latency less per pair; three subtractions more for the waves whose rays are all parallel to the plane: none in practice)
+    f3 s = o - mk(r1.x, r1.y, r1.z);
+    asm volatile("" : "+v"(s.x), "+v"(s.y), "+v"(s.z));
+    if (__builtin_fabsf(det) < 1e-8f) return;
+#else
     if (__builtin_fabsf(det) < 1e-8f) return;
     const f3 s = o - mk(r1.x, r1.y, r1.z);
+#endif
     const float t = pt_div(-dot(s, n), det);
     if (t < t_min || t > closest) return;
     const f3 p = madd(d, t, s);
@@ -208,7 +228,7 @@ PT_DEV float sphere_disc(float4 s, f3 o, f3 d) {
 // branch "did any lane hit any of the four?" instead of a divergent branch per sphere; the exact
 // sequential tests run only then.  max() drops NaNs unless all four are NaN, which is exactly the
 // NaN-ray case the reference lets through (Q10), so a NaN still reaches sphere_test.
-template <bool GROUPED, bool ANY = false>
+template <bool GROUPED, bool ANY = false, int PF = 0>      // PF: pair records requested ahead (PT_PAIR_PREFETCH; the split kernel only)
 PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int first_obj, f3 o, f3 d, float t_min,
                      float& closest, int& id) {
     if (tag == SHAPE_SPHERE) {
@@ -237,6 +257,18 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
             sphere_test<false, ANY>(s2, o, d, t_min, closest, id, first_obj + (int)i + 2);
             sphere_test<false, ANY>(s3, o, d, t_min, closest, id, first_obj + (int)i + 3);
         }
+#if PT_SPHERE_REM2
+        // of the last (n mod 4) records two reads in flight at once instead of one read per test (round 5: C2's ten spheres are two
+        // groups and two; launch 5.58 -> 5.52 ms, profiles/r05/ab_lds_latency.txt; three at once for n mod 4 = 3 spills four registers)
+        if (!GROUPED && i + 2u <= n) {
+            const float4 s0 = p[i], s1 = p[i + 1];
+            float h0, h1, d0, d1;
+            sphere_pre(s0, o, d, h0, d0); sphere_pre(s1, o, d, h1, d1);
+            sphere_post<ANY>(h0, d0, t_min, closest, id, first_obj + (int)i);
+            sphere_post<ANY>(h1, d1, t_min, closest, id, first_obj + (int)i + 1);
+            i += 2u;
+        }
+#endif
         for (; i < n; ++i) sphere_test<false, ANY>(p[i], o, d, t_min, closest, id, first_obj + (int)i);
     } else if (tag == kRunTriangle) {
         for (uint32_t i = 0; i < n; ++i) {
@@ -244,9 +276,22 @@ PT_DEV void scan_run(const float4* __restrict__ p, uint32_t tag, uint32_t n, int
             triangle_test<false, ANY>(a0, a1, a2, o, d, t_min, closest, id, first_obj + (int)i);
         }
     } else {
-        for (uint32_t i = 0; i < n; ++i) {
-            float4 a0 = p[5 * i], a1 = p[5 * i + 1], a2 = p[5 * i + 2], a3 = p[5 * i + 3], a4 = p[5 * i + 4];
-            tripair_test<ANY>(a0, a1, a2, a3, a4, o, d, t_min, closest, id, first_obj + 2 * (int)i);
+        if (PF > 0) {
+            // the next pair's plane normal is requested while this pair is tested (one of the three dependent LDS latencies of a pair
+            // test off the critical path, for three registers: kernels with registers to spare only -- k_paths_regen_split)
+            float4 a0n = p[0], a1n = p[1];
+            for (uint32_t i = 0; i < n; ++i) {
+                const float4 a0 = a0n;
+                float4 a1 = PF > 1 ? a1n : p[5 * i + 1];
+                if (i + 1u < n) { a0n = p[5 * i + 5]; if (PF > 1) a1n = p[5 * i + 6]; }
+                float4 a2 = p[5 * i + 2], a3 = p[5 * i + 3], a4 = p[5 * i + 4];
+                tripair_test<ANY>(a0, a1, a2, a3, a4, o, d, t_min, closest, id, first_obj + 2 * (int)i);
+            }
+        } else {
+            for (uint32_t i = 0; i < n; ++i) {
+                float4 a0 = p[5 * i], a1 = p[5 * i + 1], a2 = p[5 * i + 2], a3 = p[5 * i + 3], a4 = p[5 * i + 4];
+                tripair_test<ANY>(a0, a1, a2, a3, a4, o, d, t_min, closest, id, first_obj + 2 * (int)i);
+            }
         }
     }
 }
@@ -269,6 +314,9 @@ struct SceneRef {
     uint32_t n_runs, n_lights;
     BvhView bvh;
     uint32_t* stack;        // kModeBvh: LDS traversal stack, entry e of thread t at stack[e * kBlock + t]
+#if PT_RUN0_SGPR
+    Run run0;               // kModeLds: the first run record, read once per kernel into scalar registers (measured, round 5: C1 +1.7 %, C2 +0.3 %: rejected)
+#endif
 };
 template <int MODE>
 PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
@@ -286,6 +334,11 @@ PT_DEV SceneRef stage_scene(const SceneView& sc, float4* lds) {
         r.mat = lds + sc.scan_f4 + 3u * sc.n_objs;
         r.runs = reinterpret_cast<const Run*>(lds + sc.scan_f4 + 5u * sc.n_objs);
         r.lights = reinterpret_cast<const uint32_t*>(lds + sc.scan_f4 + 5u * sc.n_objs + sc.n_runs);
+#if PT_RUN0_SGPR
+        r.run0 = r.runs[0];
+        r.run0.tag = __builtin_amdgcn_readfirstlane(r.run0.tag); r.run0.first_obj = __builtin_amdgcn_readfirstlane(r.run0.first_obj);
+        r.run0.count = __builtin_amdgcn_readfirstlane(r.run0.count); r.run0.off4 = __builtin_amdgcn_readfirstlane(r.run0.off4);
+#endif
     } else {
         r.scan = lds;
         r.shape = sc.shape; r.mat = sc.mat; r.runs = sc.runs; r.lights = sc.lights;
@@ -308,20 +361,25 @@ PT_DEV void scan_global(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max
 // shrinking t_max.  kModeLds: the whole scan array already sits in LDS.  kModeTiled:
 // every run is streamed through one LDS tile; the loop is block-uniform (all
 // threads of the workgroup call this together, active or not).
-template <int MODE, bool ANY = false>
+template <int MODE, bool ANY = false, int PF = 0>
 PT_DEV void scan_closest(const SceneRef& sc, f3 o, f3 d, float t_min, float t_max, int& id_out, float& t_out) {
     constexpr bool SMALL = MODE == kModeLds;
     float closest = t_max;
     int id = -1;
     for (uint32_t r = 0; r < sc.n_runs; ++r) {
+#if PT_RUN0_SGPR
+        Run run = sc.run0;
+        if (!SMALL || r != 0u) run = sc.runs[r];
+#else
         Run run = sc.runs[r];
+#endif
         // the run record is the same in every lane: keep it (and the loop counters and object indices derived
         // from it) in scalar registers
         run.tag = __builtin_amdgcn_readfirstlane(run.tag); run.first_obj = __builtin_amdgcn_readfirstlane(run.first_obj);
         run.count = __builtin_amdgcn_readfirstlane(run.count); run.off4 = __builtin_amdgcn_readfirstlane(run.off4);
         const uint32_t per = run_entry_f4(run.tag);
         if (SMALL) {
-            scan_run<false, ANY>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
+            scan_run<false, ANY, PF>(sc.scan + run.off4, run.tag, run.count, (int)run.first_obj, o, d, t_min, closest, id);
         } else {
             float4* tile = const_cast<float4*>(sc.scan);
             const uint32_t tile_prims = kTileF4 / per;
@@ -1400,7 +1458,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
         if (n_alive != 0u) {
             // ---- plain iteration: scan #1 (rendering.rs:41)
             int id; float t;
-            scan_closest<kModeLds>(sc, p.o, p.d, a.t_min, kInf, id, t);
+            scan_closest<kModeLds, false, PT_PAIR_PREFETCH>(sc, p.o, p.d, a.t_min, kInf, id, t);
             // a Mirror vertex is not shaded here: the path waits on the special stack for a batch of its kind
             const bool special = alive && id >= 0 && is_mirror_obj(sc, id);
             const unsigned long long spm = __ballot(special);
@@ -1465,7 +1523,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                     f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
                     f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                     int sid; float st;
-                    scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                    scan_closest<kModeLds, true, PT_PAIR_PREFETCH>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
                     visible = v.need_shadow && sid < 0;
                     wave_shadow += (uint32_t)__popcll(sm);
                 }
@@ -1527,7 +1585,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                         f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
                         f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                         int sid; float st;
-                        scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                        scan_closest<kModeLds, true, PT_PAIR_PREFETCH>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
                         visible = v.need_shadow && sid < 0;
                         wave_shadow += (uint32_t)__popcll(sm);
                     }
@@ -1541,7 +1599,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
                 asm volatile("" ::: "memory");
                 int id2; float t2;
-                scan_closest<kModeLds>(sc, so, sd, a.t_min, kInf, id2, t2);
+                scan_closest<kModeLds, false, PT_PAIR_PREFETCH>(sc, so, sd, a.t_min, kInf, id2, t2);
                 const bool spec2 = qalive && id2 >= 0 && is_mirror_obj(sc, id2);
                 const bool plain2 = qalive && !spec2;
                 const unsigned long long m_p = __ballot(plain2);
@@ -1590,7 +1648,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                         f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
                         f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                         int sid; float st;
-                        scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                        scan_closest<kModeLds, true, PT_PAIR_PREFETCH>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
                         visible = v.need_shadow && sid < 0;
                         wave_shadow += (uint32_t)__popcll(sm);
                     }
@@ -1604,7 +1662,7 @@ __global__ void __launch_bounds__(kBlock, kRegenWavesSplit) k_paths_regen_split(
                 const f3 so = qalive ? q.o : parked_origin(), sd = qalive ? q.d : parked_dir();
                 asm volatile("" ::: "memory");
                 int id2; float t2;
-                scan_closest<kModeLds>(sc, so, sd, a.t_min, kInf, id2, t2);
+                scan_closest<kModeLds, false, PT_PAIR_PREFETCH>(sc, so, sd, a.t_min, kInf, id2, t2);
                 const bool spec2 = qalive && id2 >= 0 && is_mirror_obj(sc, id2);
                 const bool plain2 = qalive && !spec2;
                 const unsigned long long m_s = __ballot(spec2), m_p = __ballot(plain2);
