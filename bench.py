@@ -563,6 +563,22 @@ def main(argv=None):
                 roof["valu_insts_per_launch"] = int(prof["valu_insts_per_launch"])
             roof["counters_source"] = f"{src}: replayed from the committed rocprofv3 passes of this command ({prof.get('kernel')}, " \
                                       f"{prof.get('avg_launch_ms_kernel_trace', 0):.3f} ms per launch in the profiled process), not measured in this run"
+        if kernel.startswith("k_paths<kModeLds") and acc["p_vertices"] > 0 and avg_ms > 0:
+            # The queue form (north_star's literal organisation: SoA path queue in HBM, compacted by ballot / prefix sum) is the one
+            # kernel of this library that HBM bounds: every vertex whose path goes on writes its 64-byte state and the next pass reads
+            # it, every sample writes its 12 bytes.  `achieved` is that algorithmic traffic over the launch time against the 8 TB/s
+            # peak; the VALU figures of the same launch move to valu_*.
+            p_samples = acc["samples"] * share / n_stat / max(p_launches, 1)
+            p_vertices = acc["p_vertices"] / n_stat / max(p_launches, 1)
+            q_bytes = 128.0 * max(p_vertices - p_samples, 0.0) + 12.0 * p_samples
+            roof["valu_achieved_tflops"], roof["valu_frac"] = roof["achieved"], roof["frac"]
+            roof["bound"], roof["unit"], roof["peak"] = "hbm", "GB/s", HBM_PEAK_GBS
+            roof["achieved"] = round(q_bytes / (avg_ms * 1e-3) / 1e9, 1)
+            roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+            roof["algorithmic_bytes_per_launch"] = int(q_bytes)
+            roof["bytes_model"] = "128 B per vertex whose path goes on (64 B state written, 64 B read by the next pass) + 12 B per sample"
+            roof["kernel"] = roof["kernel"].replace("Bound by f32 VALU issue (no contraction on this path: the schema's mfma slot does not apply; "
+                                                    "same 157.3 TFLOP/s f32 peak)", "Bound by HBM (the path queue's round trip per vertex)")
         if world == 1:
             tiles = "whole image" + (" (through the single-process multi-device path: ncclCommInitAll over 1 device, ONE ncclGather, row "
                                      "permutation; frame checked bitwise against the plain render)" if mode == "multi" else "")
