@@ -168,6 +168,18 @@ uint32_t regen_blocks_per_cu_exact(const BounceArgs& a);
 uint32_t regen_blocks_per_cu_fast(const BounceArgs& a);
 void launch_paths_exact(const BounceArgs& a, uint32_t grid, hipStream_t st);
 void launch_paths_fast(const BounceArgs& a, uint32_t grid, hipStream_t st);
+// between the translation units pt_kernels.hip is built as (PT_TU there; not called by the host code): k_paths_regen_split's and the
+// BVH form's launchers live with their kernels
+int regen_split_blocks_per_cu_exact(const BounceArgs& a, size_t lds);
+int regen_split_blocks_per_cu_fast(const BounceArgs& a, size_t lds);
+void launch_regen_split_exact(const BounceArgs& b, uint32_t blocks, size_t lds, hipStream_t st);
+void launch_regen_split_fast(const BounceArgs& b, uint32_t blocks, size_t lds, hipStream_t st);
+void launch_paths_bvh_exact(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st, bool diffuse, bool list);
+void launch_paths_bvh_fast(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st, bool diffuse, bool list);
+void launch_debug_hit_bvh_exact(const SceneView& sc, uint32_t grid, size_t lds, const float* rays6, uint32_t n, float t_min, float t_max,
+                                float4* scratch, int32_t* out_id, float* out_t, float* out_rec, hipStream_t st);
+void launch_debug_hit_bvh_fast(const SceneView& sc, uint32_t grid, size_t lds, const float* rays6, uint32_t n, float t_min, float t_max,
+                               float4* scratch, int32_t* out_id, float* out_t, float* out_rec, hipStream_t st);
 
 // Film: sum the nb samples of every tile pixel in sample order into the f64
 // accumulator (world.rs:311), and when finalising write mean, sqrt-gamma and

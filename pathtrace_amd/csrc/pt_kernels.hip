@@ -43,6 +43,19 @@ using namespace ptk;
 #define PT_LAUNCH(name) name##_fast
 #endif
 
+// Translation units (round 5).  The library builds this file three times per arithmetic mode, each with the compiler options its kernels
+// measured best with (Makefile; profiles/r05/ab_noslp.txt, ab_bvh_slp.txt, ab_compiler_flags2.txt):
+//   PT_TU = 1  everything but the two below                       -fno-slp-vectorize (C2 launch -2.6 %)
+//   PT_TU = 2  k_paths_regen_split and its launcher               -fno-slp-vectorize, scheduling strategy max-ilp (C1 -1.2 %; C2 would pay 1.6 %)
+//   PT_TU = 3  the BVH form (k_paths_bvh, k_debug_hit_bvh)        with the SLP vectoriser (its 4-wide box tests pack well: +2 % without)
+//   PT_TU = 0  all of it in one unit (tools/resources.py, tools/build_variant.sh)
+// Kernel templates are instantiated where their launcher is; the launchers that cross units are declared in pt_kernels.h.
+#ifndef PT_TU
+#define PT_TU 0
+#endif
+#define PT_TU_MAIN (PT_TU == 0 || PT_TU == 1)
+#define PT_TU_SPLIT (PT_TU == 0 || PT_TU == 2)
+#define PT_TU_BVH (PT_TU == 0 || PT_TU == 3)
 #ifndef PT_PAIR_PREFETCH
 #define PT_PAIR_PREFETCH 1      // 1: the next pair's normal one pair ahead (C1 launch 7.16 -> 7.07 ms); 2: its v0 too (2 spilled registers, 7.17) -- profiles/r05/ab_lds_latency.txt
 #endif
@@ -2060,15 +2073,15 @@ __global__ void __launch_bounds__(kBlock, PT_BVH_WAVES) k_paths_bvh(BounceArgs a
     if (lane == 0u) wave_totals<MIS, !OVF>(s_totals, kBlock / 64, a.stats, wave_shadow, wave_vertices, wave_samples, wave_depth);
 }
 
-static int scene_mode(const SceneView& sc, uint32_t accel) {
+[[maybe_unused]] static int scene_mode(const SceneView& sc, uint32_t accel) {
     return accel ? kModeBvh : (sc.n_objs <= kSmallObjs ? kModeLds : kModeTiled);
 }
-static size_t scene_lds_bytes(const SceneView& sc, int mode) {
+[[maybe_unused]] static size_t scene_lds_bytes(const SceneView& sc, int mode) {
     if (mode == kModeBvh) return (size_t)(kBvhStack + 3u) * kBlock * sizeof(uint32_t);   // + 3 rows: the traversal stores a visit's (up to) three far children before it knows how many there are
     return (mode == kModeLds ? (sc.blob_f4 ? sc.blob_f4 : 1u) : kTileF4) * sizeof(float4);
 }
 template <int MODE, bool DIFFUSE, bool LIST>
-static void launch_paths_mode(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
+[[maybe_unused]] static void launch_paths_mode(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
     const bool mis = a.integrator == 0;
     const bool ovf = a.src_mode != 0u;     // continuation launch
     const dim3 g(grid), b(kBlock);
@@ -2077,8 +2090,9 @@ static void launch_paths_mode(const BounceArgs& a, uint32_t grid, size_t lds, hi
     else if (!ovf) hipLaunchKernelGGL((k_paths<MODE, false, false, DIFFUSE, LIST>), g, b, lds, st, a);
     else hipLaunchKernelGGL((k_paths<MODE, false, true, DIFFUSE, LIST>), g, b, lds, st, a);
 }
+#if PT_TU_BVH
 template <bool DIFFUSE, bool LIST>
-static void launch_paths_bvh(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
+static void launch_paths_bvh_t(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st) {
     const bool mis = a.integrator == 0;
     const bool ovf = a.src_mode != 0u;
     const dim3 g(grid), b(kBlock);
@@ -2087,19 +2101,41 @@ static void launch_paths_bvh(const BounceArgs& a, uint32_t grid, size_t lds, hip
     else if (!ovf) hipLaunchKernelGGL((k_paths_bvh<false, false, DIFFUSE, LIST>), g, b, lds, st, a);
     else hipLaunchKernelGGL((k_paths_bvh<false, true, DIFFUSE, LIST>), g, b, lds, st, a);
 }
+#endif
 
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
+#if PT_TU_BVH
+void PT_LAUNCH(launch_paths_bvh)(const BounceArgs& a, uint32_t grid, size_t lds, hipStream_t st, bool diffuse, bool list) {
+    if (list) launch_paths_bvh_t<false, true>(a, grid, lds, st);        // pixel lists: the generic kernels only
+    else if (diffuse) launch_paths_bvh_t<true, false>(a, grid, lds, st);
+    else launch_paths_bvh_t<false, false>(a, grid, lds, st);
+}
+#endif
+#if PT_TU_SPLIT
+// k_paths_regen_split for the scene's material set (the plain iterations': no OrenNayar either / no Mirror)
+typedef void (*RegenSplitKernel)(BounceArgs);
+static RegenSplitKernel regen_split_kernel(const BounceArgs& a) {
+    const bool mis = a.integrator == 0;
+    if (a.sc.no_oren_nayar) return mis ? k_paths_regen_split<true, kMatsDiffuse> : k_paths_regen_split<false, kMatsDiffuse>;
+    return mis ? k_paths_regen_split<true, kMatsNoMirror> : k_paths_regen_split<false, kMatsNoMirror>;
+}
+int PT_LAUNCH(regen_split_blocks_per_cu)(const BounceArgs& a, size_t lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_split_kernel(a), (int)kBlock, lds) != hipSuccess) return -1;
+    return n;
+}
+void PT_LAUNCH(launch_regen_split)(const BounceArgs& b, uint32_t blocks, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL(regen_split_kernel(b), dim3(blocks), dim3(kBlock), lds, st, b);
+}
+#endif
+#if PT_TU_MAIN
 // the regenerating level-0 kernel a launch takes: compiled for the scene's material set; with the Mirror vertices batched
-// (k_paths_regen_split) when the host passes exchange memory
+// (k_paths_regen_split, its own translation unit) when the host passes exchange memory
 typedef void (*RegenKernel)(BounceArgs);
 static RegenKernel regen_kernel(const BounceArgs& a) {
     const bool mis = a.integrator == 0;
-    if (a.xchg) {
-        if (a.sc.no_oren_nayar) return mis ? k_paths_regen_split<true, kMatsDiffuse> : k_paths_regen_split<false, kMatsDiffuse>;
-        return mis ? k_paths_regen_split<true, kMatsNoMirror> : k_paths_regen_split<false, kMatsNoMirror>;
-    }
     if (a.sc.diffuse_only) return mis ? k_paths_regen<true, kMatsDiffuse> : k_paths_regen<false, kMatsDiffuse>;
     if (a.sc.no_mirror) return mis ? k_paths_regen<true, kMatsNoMirror> : k_paths_regen<false, kMatsNoMirror>;
     return mis ? k_paths_regen<true, kMatsAll> : k_paths_regen<false, kMatsAll>;
@@ -2111,7 +2147,9 @@ uint32_t PT_LAUNCH(regen_blocks_per_cu)(const BounceArgs& a) {
     int n = 0;
     const size_t lds = scene_lds_bytes(a.sc, kModeLds);
     const uint32_t block = a.xchg ? kBlock : kRegenBlock;        // (the form that batches Mirror vertices keeps four waves per workgroup)
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_kernel(a), (int)block, lds) != hipSuccess || n < 0) return 0u;
+    if (a.xchg) n = PT_LAUNCH(regen_split_blocks_per_cu)(a, lds);
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, regen_kernel(a), (int)block, lds) != hipSuccess) n = -1;
+    if (n < 0) return 0u;
     return (uint32_t)n * block / kBlock;                         // in units of four waves, like the grid the host passes
 }
 void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st) {
@@ -2121,21 +2159,25 @@ void PT_LAUNCH(launch_paths)(const BounceArgs& a, uint32_t grid, hipStream_t st)
     if (a.pixels) {      // pixel-list renders: the generic kernels only (debug / replay entries, not the throughput path)
         if (mode == kModeLds) launch_paths_mode<kModeLds, false, true>(a, grid, lds, st);
         else if (mode == kModeTiled) launch_paths_mode<kModeTiled, false, true>(a, grid, lds, st);
-        else launch_paths_bvh<false, true>(a, grid, lds, st);
+        else PT_LAUNCH(launch_paths_bvh)(a, grid, lds, st, false, true);
         return;
     }
     if (mode == kModeLds && a.chunk_counter) {   // level-0 launch of a large batch: paths stay in registers (k_paths_regen*)
         const uint32_t block = a.xchg ? kBlock : kRegenBlock;    // grid = number of 4-wave units
         BounceArgs b = a;
         b.core_blocks = a.core_blocks * kBlock / block;          // (given in four-wave units like the grid)
-        hipLaunchKernelGGL(regen_kernel(a), dim3(std::max(1u, grid * kBlock / block)), dim3(block), lds, st, b);
+        const uint32_t blocks = std::max(1u, grid * kBlock / block);
+        if (a.xchg) PT_LAUNCH(launch_regen_split)(b, blocks, lds, st);
+        else hipLaunchKernelGGL(regen_kernel(a), dim3(blocks), dim3(block), lds, st, b);
         return;
     }
     if (mode == kModeLds) { if (diffuse) launch_paths_mode<kModeLds, true, false>(a, grid, lds, st); else launch_paths_mode<kModeLds, false, false>(a, grid, lds, st); }
     else if (mode == kModeTiled) launch_paths_mode<kModeTiled, false, false>(a, grid, lds, st);   // scan-dominated: the variant buys nothing (measured)
-    else { if (diffuse) launch_paths_bvh<true, false>(a, grid, lds, st); else launch_paths_bvh<false, false>(a, grid, lds, st); }
+    else PT_LAUNCH(launch_paths_bvh)(a, grid, lds, st, diffuse, false);
 }
+#endif
 }  // namespace ptk
+#if PT_TU_MAIN
 namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ film resolve
@@ -2235,6 +2277,7 @@ void launch_film_unpack(const void* recv, uint32_t W, uint32_t H, uint32_t band_
 }
 }  // namespace ptk
 #endif
+#endif      // PT_TU_MAIN
 namespace PTK_IMPL {
 
 // ------------------------------------------------------------------ debug: hit_scene on arbitrary rays
@@ -2265,6 +2308,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit(SceneView scv, const float
         if (active && out_rec) store_hit_record(sc, id, o, d, t, out_rec + 8 * (size_t)i);
     }
 }
+#if PT_TU_BVH
 // the same through the BVH: every wave packs a contiguous slice of the rays into segment form and runs
 // traverse_segment (the routine of k_paths_bvh) over it
 __global__ void __launch_bounds__(kBlock) k_debug_hit_bvh(SceneView scv, const float* __restrict__ rays6, uint32_t n,
@@ -2300,7 +2344,8 @@ __global__ void __launch_bounds__(kBlock) k_debug_hit_bvh(SceneView scv, const f
         }
     }
 }
-
+#endif      // PT_TU_BVH
+#if PT_TU_MAIN
 // ------------------------------------------------------------------ debug: the per-vertex functions on arbitrary inputs
 // One thread per item; the SAME device functions the path kernels inline (pt_device.h, sample_light_point, camera_ray).
 //   kFnBsdfEval    Material::bsdf_pdf (material.rs:86-91,139-148,221-265; mirror.rs:179-198)
@@ -2375,9 +2420,19 @@ __global__ void k_scene_setup(float4* shape, float4* mat, uint32_t n) {
     shape[3 * i] = r0; shape[3 * i + 1] = r1; shape[3 * i + 2] = r2;
     mat[2 * i + 1].w = pdf_area;
 }
+#endif      // PT_TU_MAIN
 }  // namespace PTK_IMPL
 namespace ptk {
 using namespace PTK_IMPL;
+#if PT_TU_BVH
+void PT_LAUNCH(launch_debug_hit_bvh)(const SceneView& sc, uint32_t grid, size_t lds, const float* rays6, uint32_t n, float t_min, float t_max,
+                                     float4* scratch, int32_t* out_id, float* out_t, float* out_rec, hipStream_t st) {
+    // scratch: 3 planes of n float4 (two ray planes + result)
+    hipLaunchKernelGGL(k_debug_hit_bvh, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, scratch,
+                       scratch + n, scratch + 2 * (size_t)n, out_id, out_t, out_rec);
+}
+#endif
+#if PT_TU_MAIN
 void PT_LAUNCH(launch_scene_setup)(float4* shape, float4* mat, uint32_t n, hipStream_t st) {
     if (n == 0u) return;
     hipLaunchKernelGGL(k_scene_setup, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, shape, mat, n);
@@ -2397,9 +2452,9 @@ void PT_LAUNCH(launch_debug_hit)(const SceneView& sc, uint32_t accel, const floa
         hipLaunchKernelGGL(k_debug_hit<kModeLds>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t, out_rec);
     else if (mode == kModeTiled)
         hipLaunchKernelGGL(k_debug_hit<kModeTiled>, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, out_id, out_t, out_rec);
-    else   // scratch: 3 planes of n float4 (two ray planes + result)
-        hipLaunchKernelGGL(k_debug_hit_bvh, dim3(grid), dim3(kBlock), lds, st, sc, rays6, n, t_min, t_max, scratch,
-                           scratch + n, scratch + 2 * (size_t)n, out_id, out_t, out_rec);
+    else
+        PT_LAUNCH(launch_debug_hit_bvh)(sc, grid, lds, rays6, n, t_min, t_max, scratch, out_id, out_t, out_rec, st);
 }
+#endif      // PT_TU_MAIN
 
 }  // namespace ptk

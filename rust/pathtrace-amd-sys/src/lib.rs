@@ -1,4 +1,4 @@
-//! Raw declarations of `include/pathtrace_amd.h` (ABI version 3).  Field order, types and names follow the
+//! Raw declarations of `include/pathtrace_amd.h` (ABI version 4).  Field order, types and names follow the
 //! header exactly; `tests/test_rust_binding.py` checks that.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};

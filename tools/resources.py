@@ -5,9 +5,13 @@ import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 exact = "--exact" in sys.argv
 extra = [a for a in sys.argv[1:] if a != "--exact"]
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-       f"-DPT_MATH_EXACT={1 if exact else 0}", "-Rpass-analysis=kernel-resource-usage", "-c", "pt_kernels.hip", "-o", "/dev/null"] + extra
-out = subprocess.run(cmd, cwd=os.path.join(ROOT, "pathtrace_amd", "csrc"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
+# the three translation units of the library's build, each with its options (pathtrace_amd/csrc/Makefile)
+base = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+        f"-DPT_MATH_EXACT={1 if exact else 0}", "-Rpass-analysis=kernel-resource-usage", "-c", "pt_kernels.hip", "-o", "/dev/null"]
+units = [["-fno-slp-vectorize", "-DPT_TU=1"], ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DPT_TU=2"], ["-DPT_TU=3"]]
+out = ""
+for u in units:
+    out += subprocess.run(base + u + extra, cwd=os.path.join(ROOT, "pathtrace_amd", "csrc"), stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
     m = re.search(r"remark: +(.*?) \[-Rpass", line)
