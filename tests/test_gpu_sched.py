@@ -237,3 +237,13 @@ def test_the_bench_record_verifies_itself(args):
     if "--force-multi" in args:
         x = c["exchange_copy"]
         assert x["frame_equals_single_gpu"] is True and x["value"] > 0 and c["rccl"]["ncclCommCount"] == 1
+    r = d["roofline"]
+    assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    if "--level0-form" in args:
+        # the queue form (north_star's SoA path queue in HBM) is priced against the HBM peak: 128 B per continuing vertex + 12 B per sample
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0.0 < r["valu_frac"] < 1.0
+        per_launch = 1024 * 1024 * 64 * r["vertex_share"]        # the level-0 launch's share of the job (the continuation launch takes the tails)
+        v = c["vertices_per_sample"] * per_launch
+        assert abs(r["algorithmic_bytes_per_launch"] - (128.0 * (v - per_launch) + 12.0 * per_launch)) <= 1e-3 * r["algorithmic_bytes_per_launch"]
+    else:
+        assert r["bound"] == "valu" and r["unit"] == "TFLOP/s"
