@@ -68,6 +68,9 @@ using namespace ptk;
 #ifndef PT_PAIR_S_EARLY
 #define PT_PAIR_S_EARLY 0       // measured (round 5): C1 launch 7.09 -> 7.05 / 7.17 ms without / with the prefetch -- profiles/r05/ab_pair_s_early.txt
 #endif
+#ifndef PT_U_MED3
+#define PT_U_MED3 1             // measured (round 5): C1 launch 7.04-7.07 -> 7.00-7.04 ms (two scalar instructions less per pair test) -- profiles/r05/ab_u_med3.txt
+#endif
 #ifndef PT_PAIR_FLAT
 #define PT_PAIR_FLAT 0          // measured (round 5): C1 7.46 -> 7.92 ms per launch -- profiles/r05/ab_c1_replace_flat.txt
 #endif
@@ -107,6 +110,16 @@ PT_DEV void sphere_test(float4 s, f3 o, f3 d, float t_min, float& closest, int& 
     closest = c;
     id = obj;
 }
+// RangeInclusive(0.0..=1.0).contains(u) (shape.rs:176): true for -0.0, false for NaN.  Evaluated (round 5, PT_U_MED3) as
+// "the median of (u, 0, 1) is u" -- one v_med3 + one compare instead of two compares and a scalar AND of their masks (the scalar ALU is
+// one per CU).  Equivalent for every input: a NaN is not equal to itself, and med3(-0, 0, 1) compares equal to -0 whichever zero it returns.
+PT_DEV bool in_unit_range(float u) {
+#if PT_U_MED3
+    return __builtin_amdgcn_fmed3f(u, 0.0f, 1.0f) == u;
+#else
+    return u >= 0.0f && u <= 1.0f;
+#endif
+}
 // TriangleShape::hit (shape.rs:161-192).  The reference runs Moeller-Trumbore per ray (two cross products, three dot
 // products with the edges); the f32 specification evaluates the same u, v, t from per-triangle constants built once at
 // upload (ptbvh::triangle_scan_record: plane normal n = e1 x e2 and the barycentric gradients N1, N2):
@@ -131,7 +144,7 @@ PT_DEV void triangle_test(float4 r0, float4 r1, float4 r2, f3 o, f3 d, float t_m
     if (t < t_min || t > closest) return;
     const f3 p = madd(d, t, s);                      // hit point relative to v0
     const float u = dot(p, mk(r0.w, r1.w, r2.x));
-    if (!(u >= 0.0f && u <= 1.0f)) return;         // RangeInclusive::contains: NaN rejected
+    if (!in_unit_range(u)) return;                 // RangeInclusive::contains: NaN rejected
     const float v = dot(p, mk(r2.y, r2.z, r2.w));
     if (v < 0.0f || u + v > 1.0f) return;
 #endif
@@ -178,7 +191,7 @@ PT_DEV void tripair_test(float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, 
     }
 #endif
     const float u0 = dot(p, mk(r2.x, r2.y, r2.z));
-    if (u0 >= 0.0f && u0 <= 1.0f) {
+    if (in_unit_range(u0)) {
         const float v0 = dot(p, mk(r2.w, r3.x, r3.y));
         if (!(v0 < 0.0f || u0 + v0 > 1.0f)) {
             if (ANY) { id = 0; return; }
@@ -186,7 +199,7 @@ PT_DEV void tripair_test(float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, 
         }
     }
     const float u1 = dot(p, mk(r3.z, r3.w, r4.x));
-    if (u1 >= 0.0f && u1 <= 1.0f) {
+    if (in_unit_range(u1)) {
         const float v1 = dot(p, mk(r4.y, r4.z, r4.w));
         if (!(v1 < 0.0f || u1 + v1 > 1.0f)) {
             if (ANY) { id = 0; return; }
