@@ -59,6 +59,9 @@ using namespace ptk;
 #ifndef PT_PAIR_PREFETCH
 #define PT_PAIR_PREFETCH 1      // 1: the next pair's normal one pair ahead (C1 launch 7.16 -> 7.07 ms); 2: its v0 too (2 spilled registers, 7.17) -- profiles/r05/ab_lds_latency.txt
 #endif
+#ifndef PT_PAIR_PREFETCH_GENERIC
+#define PT_PAIR_PREFETCH_GENERIC 0      // the same in the generic-material kernels (5 waves per SIMD: registers to spare)
+#endif
 #ifndef PT_SPHERE_REM2
 #define PT_SPHERE_REM2 1
 #endif
@@ -886,7 +889,7 @@ k_paths(BounceArgs a) {
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
-        scan_closest<MODE>(sc, p.o, p.d, a.t_min, kInf, id, t);
+        scan_closest<MODE, false, (MODE == kModeLds && !DIFFUSE) ? PT_PAIR_PREFETCH_GENERIC : 0>(sc, p.o, p.d, a.t_min, kInf, id, t);
         Vertex v;
         vertex_begin<MIS, DIFFUSE>(sc, p, active, id, t, sample, kx, py, v);
 
@@ -900,7 +903,7 @@ k_paths(BounceArgs a) {
                 f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
                 f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                 int sid; float st;
-                scan_closest<MODE, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);   // any-hit form
+                scan_closest<MODE, true, (MODE == kModeLds && !DIFFUSE) ? PT_PAIR_PREFETCH_GENERIC : 0>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);   // any-hit form
                 visible = v.need_shadow && sid < 0;
                 wave_shadow += (uint32_t)__popcll(__ballot(v.need_shadow));
             }
@@ -1237,7 +1240,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
 
         // ---- scan #1: closest hit of the path ray (rendering.rs:41)
         int id; float t;
-        scan_closest<kModeLds>(sc, p.o, p.d, a.t_min, kInf, id, t);
+        scan_closest<kModeLds, false, DIFFUSE == kMatsDiffuse ? 0 : PT_PAIR_PREFETCH_GENERIC>(sc, p.o, p.d, a.t_min, kInf, id, t);
         Vertex v;
         vertex_begin<MIS, DIFFUSE>(sc, p, active, id, t, sample, kx, py, v);
 
@@ -1249,7 +1252,7 @@ __global__ void __launch_bounds__(kRegenBlock, DIFFUSE == kMatsDiffuse ? kRegenW
                 f3 sdir = v.need_shadow ? v.light_dir : parked_dir();
                 f3 sorg = v.need_shadow ? v.hit.point : parked_origin();
                 int sid; float st;
-                scan_closest<kModeLds, true>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
+                scan_closest<kModeLds, true, DIFFUSE == kMatsDiffuse ? 0 : PT_PAIR_PREFETCH_GENERIC>(sc, sorg, sdir, a.t_min, v.distance - a.t_min, sid, st);
                 visible = v.need_shadow && sid < 0;
                 wave_shadow += (uint32_t)__popcll(sm);
             }
